@@ -1,0 +1,956 @@
+// piscoseg.hip -- gfx950 kernels and the C ABI of libpiscoseg.so (see include/piscoseg.h).
+//
+// Hot path of fannz00/ImageProcessing restated for MI355X:
+//   dense, HBM-bound:  k_bg_stream / k_bg_generic  (bg_correction.py:65-86 + detection.py:178-202)
+//                      k_threshold                  (detection.py:178-202 when cleaned comes from elsewhere)
+//                      k_label_fill                 (label map)
+//   sparse, on the 1-bit threshold plane: run extraction, union-find over runs, enclosure tree,
+//                      quad-count contour area, bbox, ordering (pseg_core.h; detection.py:204-216)
+//   per saved object:  cumulative filled mask window, three crops, integer sums behind the 32
+//                      region properties (detection.py:243-258, 75-159)
+// No MFMA: the path is byte/integer work bounded by HBM traffic and by latency on the sparse chain.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../include/piscoseg.h"
+#include "pseg_core.h"
+#include "synth_core.h"
+
+// ------------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------------
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+struct HostBuf {
+    std::vector<uint8_t> v;
+    template <class T> T *as(size_t n) { if (v.size() < n * sizeof(T)) v.resize(n * sizeof(T)); return (T *)v.data(); }
+};
+
+struct RowsDev {           // device SoA of the kept-object rows
+    int32_t *frame, *c, *label, *area2, *x, *y, *w, *h, *saved, *root;
+};
+
+struct pseg_ctx {
+    int device = 0, H = 0, W = 0, WW = 0, maxF = 0;
+    size_t P = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    hipEvent_t ev[8] = {};
+    float ms[6] = {};
+    // dense workspaces
+    DevBuf bits, partials, fsums, valid_dev, maskcnt, rowspans;
+    // sparse workspaces
+    DevBuf rowcnt, rowoff, framebase, ftot;      // ftot: per-frame totals {next, nkept, nsaved} and bases
+    DevBuf run_x, run_fy, fg_parent, ext, bg_parent, bg_left, minx, maxx, miny, maxy, area2, extrank,
+        keptrank, savedrank, objlabel, objflag;
+    DevBuf rows, saved_row, saved_geo, crop_off, bits_off, maskbits, sums, crops_raw, crops_masked, crops_mask, totals;
+    bool have_bits = false;       // threshold plane + masked sums already produced by the bg kernel
+    // host results
+    HostBuf h_frame_row_offset, h_frame_n_contours, h_frame_valid, h_frame_mean, h_frame_std, h_rows, h_area,
+        h_saved8, h_props, h_saved_row, h_crop_off, h_sums, h_tmp;
+    int64_t crop_bytes = 0;
+    int n_saved = 0;
+};
+
+static int fail(pseg_ctx *c, int code, const std::string &msg)
+{
+    if (c) c->err = msg;
+    return code;
+}
+#define HIPCHK(call)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (call);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return fail(ctx, PSEG_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));         \
+    } while (0)
+
+static int ensure(pseg_ctx *ctx, DevBuf &b, size_t bytes)
+{
+    if (bytes <= b.bytes) return 0;
+    if (b.p) HIPCHK(hipFree(b.p));
+    b.p = nullptr; b.bytes = 0;
+    size_t want = bytes + bytes / 4 + 256;
+    HIPCHK(hipMalloc(&b.p, want));
+    b.bytes = want;
+    return 0;
+}
+#define ENSURE(buf, bytes) do { int r_ = ensure(ctx, (buf), (bytes)); if (r_) return r_; } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// four u32 block sums -> out[0..3] (thread 0 writes); blockDim.x == 256
+__device__ __forceinline__ void block_sum4_store(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t *out)
+{
+    __shared__ uint32_t red[4][4];
+    a = wave_sum_u32(a); b = wave_sum_u32(b); c = wave_sum_u32(c); d = wave_sum_u32(d);
+    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) { red[wv][0] = a; red[wv][1] = b; red[wv][2] = c; red[wv][3] = d; }
+    __syncthreads();
+    if (threadIdx.x < 4) out[threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+__device__ __forceinline__ uint32_t bmin4(uint32_t a, uint32_t b)
+{
+    uint32_t r = 0;
+#pragma unroll
+    for (int k = 0; k < 32; k += 8) { uint32_t x = (a >> k) & 255, y = (b >> k) & 255; r |= (x < y ? x : y) << k; }
+    return r;
+}
+__device__ __forceinline__ uint32_t bmax4(uint32_t a, uint32_t b)
+{
+    uint32_t r = 0;
+#pragma unroll
+    for (int k = 0; k < 32; k += 8) { uint32_t x = (a >> k) & 255, y = (b >> k) & 255; r |= (x > y ? x : y) << k; }
+    return r;
+}
+__device__ __forceinline__ uint32_t babsdiff4(uint32_t a, uint32_t b)
+{
+    uint32_t r = 0;
+#pragma unroll
+    for (int k = 0; k < 32; k += 8) { uint32_t x = (a >> k) & 255, y = (b >> k) & 255; r |= (x > y ? x - y : y - x) << k; }
+    return r;
+}
+// per-dword tail shared by the dense kernels: corr = |img-bg| (already computed), inmask bytes
+// (0xff where mask == 255); accumulates the four sums and returns the 4 threshold bits
+__device__ __forceinline__ uint32_t tail4(uint32_t img, uint32_t corr, uint32_t inm, int thr, uint32_t &s0, uint32_t &s1,
+                                          uint32_t &s2, uint32_t &s3)
+{
+    uint32_t cm = corr & inm, bitsv = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint32_t x = (img >> (8 * k)) & 255, c = (cm >> (8 * k)) & 255;
+        s0 += x; s1 += x * x; s2 += c; s3 += c * c;
+        bitsv |= (uint32_t)((int)c > thr) << k;
+    }
+    return bitsv;
+}
+__device__ __forceinline__ uint32_t eq255_4(uint32_t m)
+{
+    uint32_t r = 0;
+#pragma unroll
+    for (int k = 0; k < 32; k += 8) r |= (((m >> k) & 255) == 255 ? 255u : 0u) << k;
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// dense kernels.  Thread = one 8-pixel strip (uint2); block = 256 threads = 2048 pixels;
+// grid = (ceil(P/2048), frames).  partials[(f*nblk+blk)*4 + {0,1,2,3}] = sum x, sum x^2 (raw frame),
+// sum c, sum c^2 (corrected inside the mask).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bg_generic(const uint8_t *__restrict__ frames, int n, int NW, size_t P,
+                                                    uint8_t *__restrict__ cleaned, const uint8_t *__restrict__ mask,
+                                                    int thr, uint8_t *__restrict__ bits8, uint32_t *__restrict__ partials)
+{
+    size_t strip = (size_t)blockIdx.x * 256 + threadIdx.x;
+    int f = blockIdx.y;
+    uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    if (strip * 8 < P) {
+        int start = (f + NW < n) ? f : n - NW;             // bg_correction.py:72 (may be negative: Python wrap)
+        auto ld = [&](int idx) { if (idx < 0) idx += n; return *(const uint2 *)(frames + (size_t)idx * P + strip * 8); };
+        uint2 prev = ld(start), bg = make_uint2(0, 0);
+        for (int j = 1; j < NW; j++) {                     // :74-78
+            uint2 cur = ld(start + j);
+            bg.x = bmax4(bg.x, bmin4(prev.x, cur.x));
+            bg.y = bmax4(bg.y, bmin4(prev.y, cur.y));
+            prev = cur;
+        }
+        uint2 img = ld(f);
+        uint2 corr = make_uint2(babsdiff4(img.x, bg.x), babsdiff4(img.y, bg.y));   // :80
+        *(uint2 *)(cleaned + (size_t)f * P + strip * 8) = make_uint2(~corr.x, ~corr.y);   // :81 (255-c == ~c)
+        uint2 inm = make_uint2(0xffffffffu, 0xffffffffu);
+        if (mask) { uint2 m = *(const uint2 *)(mask + strip * 8); inm = make_uint2(eq255_4(m.x), eq255_4(m.y)); }
+        uint32_t b = tail4(img.x, corr.x, inm.x, thr, s0, s1, s2, s3) | (tail4(img.y, corr.y, inm.y, thr, s0, s1, s2, s3) << 4);
+        bits8[(size_t)f * (P / 8) + strip] = (uint8_t)b;
+    }
+    block_sum4_store(s0, s1, s2, s3, partials + ((size_t)f * gridDim.x + blockIdx.x) * 4);
+}
+
+// detection.py:178-202 for a cleaned image that did not come from k_bg_* (e.g. after deconvolution)
+__global__ __launch_bounds__(256) void k_threshold(const uint8_t *__restrict__ cleaned, size_t P, const uint8_t *__restrict__ mask,
+                                                   int thr, uint8_t *__restrict__ bits8, uint32_t *__restrict__ partials)
+{
+    size_t strip = (size_t)blockIdx.x * 256 + threadIdx.x;
+    int f = blockIdx.y;
+    uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    if (strip * 8 < P) {
+        uint2 cl = *(const uint2 *)(cleaned + (size_t)f * P + strip * 8);
+        uint2 corr = make_uint2(~cl.x, ~cl.y);
+        uint2 inm = make_uint2(0xffffffffu, 0xffffffffu);
+        if (mask) { uint2 m = *(const uint2 *)(mask + strip * 8); inm = make_uint2(eq255_4(m.x), eq255_4(m.y)); }
+        uint32_t b = tail4(cl.x, corr.x, inm.x, thr, s0, s1, s2, s3) | (tail4(cl.y, corr.y, inm.y, thr, s0, s1, s2, s3) << 4);
+        bits8[(size_t)f * (P / 8) + strip] = (uint8_t)b;
+    }
+    block_sum4_store(s0, s1, s2, s3, partials + ((size_t)f * gridDim.x + blockIdx.x) * 4);
+}
+
+// per-frame reduction of the block partials; fsums[f*4+k] u64.  If setvalid: valid[f] = std > 2,
+// decided exactly in integers: P*sum(x^2) - sum(x)^2 > 4*P^2   (bg_correction.py:71)
+__global__ __launch_bounds__(256) void k_reduce_partials(const uint32_t *__restrict__ partials, int nblk, unsigned long long P,
+                                                         unsigned long long *__restrict__ fsums, uint8_t *__restrict__ valid,
+                                                         int setvalid, int first, int count)
+{
+    __shared__ unsigned long long red[4][4];
+    int f = blockIdx.x;
+    unsigned long long a[4] = {0, 0, 0, 0};
+    for (int b = threadIdx.x; b < nblk; b += 256) {
+        const uint32_t *p = partials + ((size_t)f * nblk + b) * 4;
+#pragma unroll
+        for (int k = 0; k < 4; k++) a[k] += p[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        for (int o = 32; o > 0; o >>= 1) a[k] += __shfl_down(a[k], o, 64);
+    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) for (int k = 0; k < 4; k++) red[wv][k] = a[k];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long s[4];
+        for (int k = 0; k < 4; k++) s[k] = red[0][k] + red[1][k] + red[2][k] + red[3][k];
+        for (int k = first; k < first + count; k++) fsums[(size_t)f * 4 + k] = s[k];
+        if (setvalid) valid[f] = (P * s[1] - s[0] * s[0]) > 4ull * P * P;
+    }
+}
+
+__global__ void k_mask_count(const uint8_t *__restrict__ mask, size_t P, unsigned long long *cnt)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t c = 0;
+    if (i * 8 < P) { uint2 m = *(const uint2 *)(mask + i * 8); c = __popc(eq255_4(m.x) & 0x01010101u) + __popc(eq255_4(m.y) & 0x01010101u); }
+    c = wave_sum_u32(c);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(cnt, (unsigned long long)c);
+}
+
+__global__ void k_fill_spans(uint8_t *mask, int H, int W, const int32_t *spans)
+{
+    int y = blockIdx.x;
+    int xa = spans[2 * y], xb = spans[2 * y + 1];
+    for (int x = threadIdx.x; x < W; x += blockDim.x) mask[(size_t)y * W + x] = (x >= xa && x <= xb) ? 255 : 0;
+}
+
+__global__ void k_synth(uint8_t *out, int H, int W, int frame0, unsigned long long seed, const int32_t *objs, const int32_t *foff)
+{
+    int f = blockIdx.y;
+    size_t P = (size_t)H * W;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    int y = (int)(i / W), x = (int)(i % W);
+    int v = synth_background(x, y, H, W, seed, frame0 + f);
+    for (int k = foff[f]; k < foff[f + 1]; k++) v -= synth_object_hit(objs + 8 * (size_t)k, x, y);
+    out[(size_t)f * P + i] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+}
+
+// ------------------------------------------------------------------------------------------------
+// sparse kernels: wrappers around pseg_core.h bodies
+// ------------------------------------------------------------------------------------------------
+#define GTID ((size_t)blockIdx.x * blockDim.x + threadIdx.x)
+__global__ void k_count_runs(SegState S, size_t n) { size_t g = GTID; if (g < n) count_runs_body(S, g); }
+__global__ void k_fill_runs(SegState S, size_t n) { size_t g = GTID; if (g < n) fill_runs_body(S, g); }
+__global__ void k_init_runs(SegState S, int nfg, int nbg)
+{
+    size_t g = GTID;
+    if (g < (size_t)nfg) init_run_body(S, (int)g);
+    if (g < (size_t)nbg) init_bg_body(S, (int)g);
+}
+__global__ void k_fg_union(SegState S, int nfg) { size_t g = GTID; if (g < (size_t)nfg) fg_union_body(S, (int)g); }
+__global__ void k_bg_union(SegState S, int nfg, int nt) { size_t g = GTID; if (g < (size_t)nt) bg_union_body(S, (int)g, nfg); }
+__global__ void k_flatten(SegState S, int nfg, int nbg)
+{
+    size_t g = GTID;
+    if (g < (size_t)nfg) flatten_body(S.fg_parent, (int)g);
+    if (g < (size_t)nbg) flatten_body(S.bg_parent, (int)g);
+}
+__global__ void k_resolve_ext(SegState S, int nfg) { size_t g = GTID; if (g < (size_t)nfg) resolve_ext_body(S, (int)g); }
+__global__ void k_bbox(SegState S, int nfg) { size_t g = GTID; if (g < (size_t)nfg) bbox_body(S, (int)g); }
+__global__ void k_area(SegState S, int nfy) { size_t g = GTID; if (g < (size_t)nfy) area_body(S, (int)g); }
+
+// exclusive scan of rowcnt inside each frame (block per frame); ftot[f] = runs in frame f
+__global__ __launch_bounds__(256) void k_scan_rows(SegState S, uint32_t *ftot)
+{
+    __shared__ uint32_t sh[256];
+    __shared__ uint32_t carry;
+    int f = blockIdx.x, H = S.H;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < H; base += 256) {
+        int y = base + threadIdx.x;
+        uint32_t v = y < H ? S.rowcnt[(size_t)f * H + y] : 0;
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 1; o < 256; o <<= 1) {
+            uint32_t t = threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
+            __syncthreads();
+            sh[threadIdx.x] += t;
+            __syncthreads();
+        }
+        uint32_t incl = sh[threadIdx.x], c0 = carry;
+        if (y < H) S.rowoff[(size_t)f * (H + 1) + y] = c0 + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 255) carry = c0 + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { S.rowoff[(size_t)f * (H + 1) + H] = carry; ftot[f] = carry; }
+}
+
+// exclusive scan over <= a few thousand frames by one block: out[0..F], k interleaved columns
+__global__ void k_scan_small(const uint32_t *in, uint32_t *out, int F, int stride_in, int stride_out)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        uint32_t acc = 0;
+        for (int f = 0; f < F; f++) { out[(size_t)f * stride_out] = acc; acc += in[(size_t)f * stride_in]; }
+        out[(size_t)F * stride_out] = acc;
+    }
+}
+
+// ranks of external roots / kept / saved objects inside each frame (block per frame).
+// ftot3[f*3+{0,1,2}] = number of external contours, kept, saved.
+__global__ __launch_bounds__(256) void k_rank(SegState S, double min_seg, double min_save, uint32_t *ftot3)
+{
+    __shared__ uint32_t sh[3][256];
+    __shared__ uint32_t carry[3];
+    int f = blockIdx.x;
+    int r0 = (int)S.framebase[f], r1 = (int)S.framebase[f + 1];
+    if (threadIdx.x < 3) carry[threadIdx.x] = 0;
+    __syncthreads();
+    for (int base = r0; base < r1; base += 256) {
+        int r = base + threadIdx.x;
+        uint32_t v[3] = {0, 0, 0};
+        if (r < r1 && is_ext_root(S, r)) {
+            double area = 0.5 * (double)S.area2[r];
+            v[0] = 1;
+            v[1] = !(area < min_seg);                       // detection.py:223 ("< -> continue")
+            v[2] = v[1] && (area > min_save);               // detection.py:235
+        }
+        for (int k = 0; k < 3; k++) sh[k][threadIdx.x] = v[k];
+        __syncthreads();
+        for (int o = 1; o < 256; o <<= 1) {
+            uint32_t t[3];
+            for (int k = 0; k < 3; k++) t[k] = threadIdx.x >= o ? sh[k][threadIdx.x - o] : 0;
+            __syncthreads();
+            for (int k = 0; k < 3; k++) sh[k][threadIdx.x] += t[k];
+            __syncthreads();
+        }
+        uint32_t c0[3] = {carry[0], carry[1], carry[2]};
+        if (r < r1) {
+            S.extrank[r] = (int32_t)(c0[0] + sh[0][threadIdx.x] - v[0]);
+            S.keptrank[r] = (int32_t)(c0[1] + sh[1][threadIdx.x] - v[1]);
+            S.savedrank[r] = (int32_t)(c0[2] + sh[2][threadIdx.x] - v[2]);
+        }
+        __syncthreads();
+        if (threadIdx.x == 255) for (int k = 0; k < 3; k++) carry[k] = c0[k] + sh[k][255];
+        __syncthreads();
+    }
+    if (threadIdx.x < 3) ftot3[f * 3 + threadIdx.x] = carry[threadIdx.x];
+}
+
+// one row per kept object, ordered (frame, c); c counts from the LAST external root (detection.py:222)
+__global__ void k_emit(SegState S, int nfg, double min_seg, double min_save, const uint32_t *ftot3, const uint32_t *rowbase,
+                       const uint32_t *savedbase, RowsDev R, int32_t *objlabel, int32_t *objflag, int32_t *saved_row)
+{
+    size_t g = GTID;
+    if (g >= (size_t)nfg) return;
+    int r = (int)g;
+    objflag[r] = 0;
+    objlabel[r] = 0;
+    if (!is_ext_root(S, r)) return;
+    int f = (int)(S.run_fy[r] >> 16);
+    int next = (int)ftot3[f * 3], nkept = (int)ftot3[f * 3 + 1], nsaved = (int)ftot3[f * 3 + 2];
+    int label = next - S.extrank[r];
+    objlabel[r] = label;
+    double area = 0.5 * (double)S.area2[r];
+    if (area < min_seg) return;
+    bool saved = area > min_save;
+    int c = nkept - 1 - S.keptrank[r];
+    int i = (int)rowbase[f] + c;
+    R.frame[i] = f; R.c[i] = c; R.label[i] = label; R.area2[i] = S.area2[r];
+    R.x[i] = S.minx[r]; R.y[i] = S.miny[r];
+    R.w[i] = S.maxx[r] - S.minx[r] + 1; R.h[i] = S.maxy[r] - S.miny[r] + 1;
+    R.saved[i] = saved; R.root[i] = r;
+    objflag[r] = 1 | (saved ? 2 : 0);
+    if (saved) saved_row[(int)savedbase[f] + (nsaved - 1 - S.savedrank[r])] = i;
+}
+
+// label map: zero fill is done by a memset; thread per run writes its label
+__global__ void k_label_runs(SegState S, int nfg, const int32_t *objlabel, int32_t *labels)
+{
+    size_t g = GTID;
+    if (g >= (size_t)nfg) return;
+    int r = (int)g;
+    int E = S.ext[r];
+    if (S.fg_parent[r] != E) return;                        // component nested in a hole: label 0
+    int lab = objlabel[E];
+    int y = (int)(S.run_fy[r] & 0xffffu), f = (int)(S.run_fy[r] >> 16);
+    int32_t *row = labels + ((size_t)f * S.H + y) * S.W;
+    for (int x = run_xs(S, r); x <= run_xe(S, r); x++) row[x] = lab;
+}
+
+// geometry of saved object s: saved_geo[s*8] = f, x, y, w, h, root, words-per-row, 0 ; sizes for the scans
+__global__ void k_saved_geo(int n_saved, const int32_t *saved_row, RowsDev R, int32_t *geo, unsigned long long *sz)
+{
+    size_t g = GTID;
+    if (g >= (size_t)n_saved) return;
+    int i = saved_row[g];
+    int w = R.w[i], h = R.h[i], wpr = (w + 31) >> 5;
+    int32_t *o = geo + 8 * g;
+    o[0] = R.frame[i]; o[1] = R.x[i]; o[2] = R.y[i]; o[3] = w; o[4] = h; o[5] = R.root[i]; o[6] = wpr; o[7] = i;
+    sz[2 * g] = (unsigned long long)w * h;
+    sz[2 * g + 1] = (unsigned long long)wpr * h;
+}
+__global__ void k_scan_sizes(const unsigned long long *sz, int n, long long *crop_off, long long *bits_off)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        long long a = 0, b = 0;
+        for (int s = 0; s < n; s++) { crop_off[s] = a; bits_off[s] = b; a += (long long)sz[2 * s]; b += (long long)sz[2 * s + 1]; }
+        crop_off[n] = a; bits_off[n] = b;
+    }
+}
+
+// cumulative filled mask window of saved object s as bits (block per object, thread per 32-px word).
+// A pixel is set iff it belongs to the hole-filled region of a SAVED object iterated at or before
+// this one (root index >= own root): detection.py:206,245-246 (the shared mask accumulates).
+__global__ __launch_bounds__(256) void k_build_masks(SegState S, const int32_t *geo, const long long *bits_off,
+                                                     const int32_t *objflag, uint32_t *maskbits)
+{
+    int s = blockIdx.x;
+    const int32_t *o = geo + 8 * (size_t)s;
+    int f = o[0], bx = o[1], by = o[2], w = o[3], h = o[4], root = o[5], wpr = o[6];
+    uint32_t *mb = maskbits + bits_off[s];
+    for (int wi = threadIdx.x; wi < wpr * h; wi += blockDim.x) {
+        int yy = wi / wpr, wx = wi - yy * wpr;
+        int x0 = bx + 32 * wx, x1 = x0 + 31;
+        if (x1 > bx + w - 1) x1 = bx + w - 1;
+        int y = by + yy;
+        uint32_t bitsv = mask_word_body(S, objflag, f, y, x0, x1, root);
+        mb[wi] = bitsv;
+    }
+}
+
+__device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v, unsigned long long *sh)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// three crops + integer sums of saved object s (block per object).
+// sums[s*PSEG_NSUMS + k]: 0 N, 1 sum r, 2 sum c, 3 sum r^2, 4 sum c^2, 5 sum r*c, 6 min I, 7 max I, 8 sum I,
+//   9 filled area, 10..12 perimeter code counts (weight 1, sqrt2, (1+sqrt2)/2), 13 euler, 14 convex area
+__global__ __launch_bounds__(256) void k_crops_sums(SegState S, const int32_t *geo, const long long *crop_off,
+                                                    const long long *bits_off, const uint32_t *maskbits,
+                                                    const uint8_t *cleaned, const uint8_t *raw, uint8_t *c_raw,
+                                                    uint8_t *c_masked, uint8_t *c_mask, long long *sums)
+{
+    __shared__ unsigned long long sh[4];
+    __shared__ uint32_t shmm[2][4];
+    int s = blockIdx.x;
+    const int32_t *o = geo + 8 * (size_t)s;
+    int f = o[0], bx = o[1], by = o[2], w = o[3], h = o[4], wpr = o[6];
+    const uint32_t *mb = maskbits + bits_off[s];
+    size_t P = (size_t)S.H * S.W;
+    const uint8_t *cl = cleaned + (size_t)f * P, *rw = raw + (size_t)f * P;
+    long long off = crop_off[s];
+    unsigned long long a[7] = {0, 0, 0, 0, 0, 0, 0};
+    uint32_t imin = 255, imax = 0;
+    int np = w * h;
+    for (int p = threadIdx.x; p < np; p += blockDim.x) {
+        int yy = p / w, xx = p - yy * w;
+        uint32_t bit = (mb[yy * wpr + (xx >> 5)] >> (xx & 31)) & 1u;
+        size_t gi = (size_t)(by + yy) * S.W + bx + xx;
+        uint8_t cv = cl[gi];
+        c_raw[off + p] = rw[gi];
+        c_mask[off + p] = bit ? 255 : 0;
+        c_masked[off + p] = bit ? cv : 255;
+        if (bit) {
+            a[0] += 1; a[1] += yy; a[2] += xx;
+            a[3] += (unsigned long long)yy * yy; a[4] += (unsigned long long)xx * xx; a[5] += (unsigned long long)yy * xx;
+            a[6] += cv;
+            imin = cv < imin ? cv : imin; imax = cv > imax ? cv : imax;
+        }
+    }
+    unsigned long long tot[7];
+    for (int k = 0; k < 7; k++) tot[k] = block_sum_u64(a[k], sh);
+    for (int o2 = 32; o2 > 0; o2 >>= 1) {
+        uint32_t t0 = __shfl_down(imin, o2, 64), t1 = __shfl_down(imax, o2, 64);
+        imin = t0 < imin ? t0 : imin; imax = t1 > imax ? t1 : imax;
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { shmm[0][threadIdx.x >> 6] = imin; shmm[1][threadIdx.x >> 6] = imax; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long *q = sums + (size_t)s * PSEG_NSUMS;
+        uint32_t mn = 255, mx = 0;
+        for (int k = 0; k < 4; k++) { mn = shmm[0][k] < mn ? shmm[0][k] : mn; mx = shmm[1][k] > mx ? shmm[1][k] : mx; }
+        q[0] = (long long)tot[0]; q[1] = (long long)tot[1]; q[2] = (long long)tot[2]; q[3] = (long long)tot[3];
+        q[4] = (long long)tot[4]; q[5] = (long long)tot[5]; q[6] = mn; q[7] = mx; q[8] = (long long)tot[6];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+static inline unsigned nblocks(size_t n, unsigned bs = 256) { return (unsigned)((n + bs - 1) / bs); }
+
+extern "C" int pseg_create(int device, int H, int W, int max_frames, pseg_ctx **out)
+{
+    if (!out) return PSEG_ERR_ARG;
+    *out = nullptr;
+    pseg_ctx *ctx = new pseg_ctx();
+    if (H < 2 || W < 64 || (W % 64) || H > 65535 || W > 32768 || max_frames < 1 || max_frames > 65535) {
+        delete ctx;
+        return PSEG_ERR_ARG;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device || device < 0) { delete ctx; return PSEG_ERR_NODEVICE; }
+    ctx->device = device; ctx->H = H; ctx->W = W; ctx->WW = W / 64; ctx->maxF = max_frames; ctx->P = (size_t)H * W;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&ctx->stream) != hipSuccess) { delete ctx; return PSEG_ERR_HIP; }
+    ctx->own_stream = true;
+    for (auto &e : ctx->ev) if (hipEventCreate(&e) != hipSuccess) { delete ctx; return PSEG_ERR_HIP; }
+    *out = ctx;
+    return PSEG_OK;
+}
+
+extern "C" int pseg_destroy(pseg_ctx *ctx)
+{
+    if (!ctx) return PSEG_ERR_ARG;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    DevBuf *bufs[] = {&ctx->bits, &ctx->partials, &ctx->fsums, &ctx->valid_dev, &ctx->maskcnt, &ctx->rowspans, &ctx->rowcnt,
+                      &ctx->rowoff, &ctx->framebase, &ctx->ftot, &ctx->run_x, &ctx->run_fy, &ctx->fg_parent, &ctx->ext,
+                      &ctx->bg_parent, &ctx->bg_left, &ctx->minx, &ctx->maxx, &ctx->miny, &ctx->maxy, &ctx->area2,
+                      &ctx->extrank, &ctx->keptrank, &ctx->savedrank, &ctx->objlabel, &ctx->objflag, &ctx->rows,
+                      &ctx->saved_row, &ctx->saved_geo, &ctx->crop_off, &ctx->bits_off, &ctx->maskbits, &ctx->sums,
+                      &ctx->crops_raw, &ctx->crops_masked, &ctx->crops_mask, &ctx->totals};
+    for (DevBuf *b : bufs) if (b->p) hipFree(b->p);
+    for (auto &e : ctx->ev) if (e) hipEventDestroy(e);
+    if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return PSEG_OK;
+}
+
+extern "C" const char *pseg_last_error(const pseg_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+extern "C" float pseg_last_ms(const pseg_ctx *ctx, int which) { return (ctx && which >= 0 && which < 6) ? ctx->ms[which] : -1.f; }
+
+extern "C" int pseg_set_stream(pseg_ctx *ctx, void *hip_stream)
+{
+    if (!ctx) return PSEG_ERR_ARG;
+    if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
+    ctx->stream = (hipStream_t)hip_stream;
+    ctx->own_stream = false;
+    return PSEG_OK;
+}
+
+static int check_batch(pseg_ctx *ctx, int n)
+{
+    if (!ctx) return PSEG_ERR_ARG;
+    if (n < 1 || n > ctx->maxF) return fail(ctx, PSEG_ERR_ARG, "n out of range for this context");
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e != hipSuccess) return fail(ctx, PSEG_ERR_HIP, hipGetErrorString(e));
+    return 0;
+}
+
+// background kernel launch (+ reduction of the raw sums; masked sums too when fused)
+static int run_bg(pseg_ctx *ctx, const uint8_t *frames, int n, int n_bg_imgs, const uint8_t *mask, int thr, uint8_t *cleaned)
+{
+    int NW = 2 * n_bg_imgs;                                   // bg_correction.py:65
+    if (n_bg_imgs < 1 || 2 * n < NW) return fail(ctx, PSEG_ERR_ARG, "need n >= n_bg_imgs (reference raises IndexError below that)");
+    size_t P = ctx->P;
+    unsigned nblk = nblocks(P / 8);
+    ENSURE(ctx->bits, (size_t)n * P / 8);
+    ENSURE(ctx->partials, (size_t)n * nblk * 4 * sizeof(uint32_t));
+    ENSURE(ctx->fsums, (size_t)n * 4 * sizeof(uint64_t));
+    ENSURE(ctx->valid_dev, (size_t)n);
+    HIPCHK(hipEventRecord(ctx->ev[0], ctx->stream));
+    hipLaunchKernelGGL(k_bg_generic, dim3(nblk, n), dim3(256), 0, ctx->stream, frames, n, NW, P, cleaned, mask, thr,
+                       (uint8_t *)ctx->bits.p, (uint32_t *)ctx->partials.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
+    hipLaunchKernelGGL(k_reduce_partials, dim3(n), dim3(256), 0, ctx->stream, (const uint32_t *)ctx->partials.p, (int)nblk,
+                       (unsigned long long)P, (unsigned long long *)ctx->fsums.p, (uint8_t *)ctx->valid_dev.p, 1, 0, 4);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+static void finish_meanstd(const uint64_t *s, double cnt, double *mean, double *std_)
+{
+    // exact integers: var = (cnt*sum2 - sum^2) / cnt^2
+    double m = (double)s[0] / cnt;
+    long double num = (long double)cnt * (long double)s[1] - (long double)s[0] * (long double)s[0];
+    double var = (double)(num / ((long double)cnt * (long double)cnt));
+    *mean = m;
+    *std_ = sqrt(var < 0 ? 0 : var);
+}
+
+static int fetch_raw_stats(pseg_ctx *ctx, int n, double *mean_std, uint8_t *valid)
+{
+    uint64_t *hs = ctx->h_tmp.as<uint64_t>((size_t)n * 4 + n);
+    uint8_t *hv = (uint8_t *)(hs + (size_t)n * 4);
+    HIPCHK(hipMemcpyAsync(hs, ctx->fsums.p, (size_t)n * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(hv, ctx->valid_dev.p, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (int f = 0; f < n; f++) {
+        if (mean_std) finish_meanstd(hs + 4 * f, (double)ctx->P, &mean_std[2 * f], &mean_std[2 * f + 1]);
+        if (valid) valid[f] = hv[f];
+    }
+    return 0;
+}
+
+extern "C" int pseg_bgcorrect(pseg_ctx *ctx, const uint8_t *frames, int n, int n_bg_imgs, uint8_t *cleaned, double *mean_std,
+                              uint8_t *valid)
+{
+    int r = check_batch(ctx, n);
+    if (r) return r;
+    if (!frames || !cleaned) return fail(ctx, PSEG_ERR_ARG, "null frame pointer");
+    ctx->have_bits = false;
+    r = run_bg(ctx, frames, n, n_bg_imgs, nullptr, 255, cleaned);
+    if (r) return r;
+    r = fetch_raw_stats(ctx, n, mean_std, valid);
+    if (r) return r;
+    HIPCHK(hipEventElapsedTime(&ctx->ms[0], ctx->ev[0], ctx->ev[1]));
+    return PSEG_OK;
+}
+
+// everything after the threshold plane exists.  valid flags are in ctx->valid_dev.
+static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw, const uint8_t *mask, int n,
+                      double min_seg, double min_save, int32_t *labels, pseg_table *out)
+{
+    const int H = ctx->H, W = ctx->W, WW = ctx->WW;
+    const size_t P = ctx->P;
+    hipStream_t st = ctx->stream;
+    SegState S;
+    memset(&S, 0, sizeof(S));
+    S.F = n; S.H = H; S.W = W; S.WW = WW;
+    S.bits = (const uint64_t *)ctx->bits.p;
+    S.valid = (const uint8_t *)ctx->valid_dev.p;
+    ENSURE(ctx->rowcnt, (size_t)n * H * 4);
+    ENSURE(ctx->rowoff, (size_t)n * (H + 1) * 4);
+    ENSURE(ctx->framebase, (size_t)(n + 1) * 4);
+    ENSURE(ctx->ftot, (size_t)(n + 1) * 4 * 8);
+    ENSURE(ctx->maskcnt, 64);
+    ENSURE(ctx->totals, 256);
+    S.rowcnt = (uint32_t *)ctx->rowcnt.p; S.rowoff = (uint32_t *)ctx->rowoff.p; S.framebase = (uint32_t *)ctx->framebase.p;
+    uint32_t *ftot = (uint32_t *)ctx->ftot.p;            // [n] run totals | [3n] rank totals | [n+1] rowbase | [n+1] savedbase
+    uint32_t *ftot3 = ftot + n, *rowbase = ftot3 + 3 * (size_t)n, *savedbase = rowbase + (n + 1);
+
+    HIPCHK(hipEventRecord(ctx->ev[2], st));
+    if (mask) {
+        HIPCHK(hipMemsetAsync(ctx->maskcnt.p, 0, 8, st));
+        hipLaunchKernelGGL(k_mask_count, dim3(nblocks(P / 8)), dim3(256), 0, st, mask, P, (unsigned long long *)ctx->maskcnt.p);
+    }
+    HIPCHK(hipMemsetAsync(S.rowcnt, 0, (size_t)n * H * 4, st));
+    size_t nwords = (size_t)n * H * WW;
+    hipLaunchKernelGGL(k_count_runs, dim3(nblocks(nwords)), dim3(256), 0, st, S, nwords);
+    hipLaunchKernelGGL(k_scan_rows, dim3(n), dim3(256), 0, st, S, ftot);
+    hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(64), 0, st, (const uint32_t *)ftot, S.framebase, n, 1, 1);
+    HIPCHK(hipGetLastError());
+    uint32_t nfg_u = 0;
+    HIPCHK(hipMemcpyAsync(&nfg_u, S.framebase + n, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (nfg_u > 0x3fffffffu) return fail(ctx, PSEG_ERR_CAPACITY, "too many foreground runs");
+    const int nfg = (int)nfg_u, nbg = nfg + n * H;
+    const size_t cap = (size_t)(nfg > 0 ? nfg : 1);
+    ENSURE(ctx->run_x, cap * 4); ENSURE(ctx->run_fy, cap * 4); ENSURE(ctx->fg_parent, cap * 4); ENSURE(ctx->ext, cap * 4);
+    ENSURE(ctx->bg_parent, (size_t)nbg * 4); ENSURE(ctx->bg_left, (size_t)nbg * 4);
+    ENSURE(ctx->minx, cap * 4); ENSURE(ctx->maxx, cap * 4); ENSURE(ctx->miny, cap * 4); ENSURE(ctx->maxy, cap * 4);
+    ENSURE(ctx->area2, cap * 4); ENSURE(ctx->extrank, cap * 4); ENSURE(ctx->keptrank, cap * 4); ENSURE(ctx->savedrank, cap * 4);
+    ENSURE(ctx->objlabel, cap * 4); ENSURE(ctx->objflag, cap * 4);
+    S.run_x = (uint32_t *)ctx->run_x.p; S.run_fy = (uint32_t *)ctx->run_fy.p;
+    S.fg_parent = (int32_t *)ctx->fg_parent.p; S.ext = (int32_t *)ctx->ext.p;
+    S.bg_parent = (int32_t *)ctx->bg_parent.p; S.bg_left = (int32_t *)ctx->bg_left.p;
+    S.minx = (int32_t *)ctx->minx.p; S.maxx = (int32_t *)ctx->maxx.p; S.miny = (int32_t *)ctx->miny.p; S.maxy = (int32_t *)ctx->maxy.p;
+    S.area2 = (int32_t *)ctx->area2.p;
+    S.extrank = (int32_t *)ctx->extrank.p; S.keptrank = (int32_t *)ctx->keptrank.p; S.savedrank = (int32_t *)ctx->savedrank.p;
+    int32_t *objlabel = (int32_t *)ctx->objlabel.p, *objflag = (int32_t *)ctx->objflag.p;
+
+    hipLaunchKernelGGL(k_init_runs, dim3(nblocks(nbg)), dim3(256), 0, st, S, nfg, nbg);
+    if (nfg > 0) {
+        hipLaunchKernelGGL(k_fill_runs, dim3(nblocks(nwords)), dim3(256), 0, st, S, nwords);
+        hipLaunchKernelGGL(k_fg_union, dim3(nblocks(nfg)), dim3(256), 0, st, S, nfg);
+    }
+    hipLaunchKernelGGL(k_bg_union, dim3(nblocks(nbg)), dim3(256), 0, st, S, nfg, nbg);
+    hipLaunchKernelGGL(k_flatten, dim3(nblocks(nbg)), dim3(256), 0, st, S, nfg, nbg);
+    if (nfg > 0) {
+        hipLaunchKernelGGL(k_resolve_ext, dim3(nblocks(nfg)), dim3(256), 0, st, S, nfg);
+        hipLaunchKernelGGL(k_bbox, dim3(nblocks(nfg)), dim3(256), 0, st, S, nfg);
+        hipLaunchKernelGGL(k_area, dim3(nblocks((size_t)n * H)), dim3(256), 0, st, S, n * H);
+    }
+    hipLaunchKernelGGL(k_rank, dim3(n), dim3(256), 0, st, S, min_seg, min_save, ftot3);
+    hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(64), 0, st, (const uint32_t *)(ftot3 + 1), rowbase, n, 3, 1);
+    hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(64), 0, st, (const uint32_t *)(ftot3 + 2), savedbase, n, 3, 1);
+    HIPCHK(hipGetLastError());
+    // host copies of the per-frame tables
+    uint32_t *h_ft = ctx->h_tmp.as<uint32_t>((size_t)n * 8 + 16);
+    HIPCHK(hipMemcpyAsync(h_ft, ftot3, ((size_t)3 * n + 2 * (n + 1)) * 4, hipMemcpyDeviceToHost, st));
+    std::vector<uint64_t> fs((size_t)n * 4);
+    uint64_t h_maskcnt = (uint64_t)P;
+    HIPCHK(hipMemcpyAsync(fs.data(), ctx->fsums.p, (size_t)n * 4 * 8, hipMemcpyDeviceToHost, st));
+    if (mask) HIPCHK(hipMemcpyAsync(&h_maskcnt, ctx->maskcnt.p, 8, hipMemcpyDeviceToHost, st));
+    std::vector<uint8_t> hvalid(n);
+    HIPCHK(hipMemcpyAsync(hvalid.data(), ctx->valid_dev.p, n, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    const uint32_t *h_ftot3 = h_ft, *h_rowbase = h_ft + 3 * (size_t)n, *h_savedbase = h_rowbase + (n + 1);
+    const int n_rows = (int)h_rowbase[n], n_saved = (int)h_savedbase[n];
+
+    // rows
+    const size_t rcap = (size_t)(n_rows > 0 ? n_rows : 1), scap = (size_t)(n_saved > 0 ? n_saved : 1);
+    ENSURE(ctx->rows, rcap * 10 * 4);
+    ENSURE(ctx->saved_row, scap * 4);
+    ENSURE(ctx->saved_geo, scap * 8 * 4 + scap * 2 * 8);
+    ENSURE(ctx->crop_off, (scap + 1) * 8);
+    ENSURE(ctx->bits_off, (scap + 1) * 8);
+    ENSURE(ctx->sums, scap * PSEG_NSUMS * 8);
+    RowsDev R;
+    {
+        int32_t *b = (int32_t *)ctx->rows.p;
+        R.frame = b; R.c = b + rcap; R.label = b + 2 * rcap; R.area2 = b + 3 * rcap; R.x = b + 4 * rcap; R.y = b + 5 * rcap;
+        R.w = b + 6 * rcap; R.h = b + 7 * rcap; R.saved = b + 8 * rcap; R.root = b + 9 * rcap;
+    }
+    int32_t *saved_row = (int32_t *)ctx->saved_row.p;
+    int32_t *geo = (int32_t *)ctx->saved_geo.p;
+    unsigned long long *sz = (unsigned long long *)(geo + 8 * scap);
+    if (nfg > 0) {
+        hipLaunchKernelGGL(k_emit, dim3(nblocks(nfg)), dim3(256), 0, st, S, nfg, min_seg, min_save, (const uint32_t *)ftot3,
+                           (const uint32_t *)rowbase, (const uint32_t *)savedbase, R, objlabel, objflag, saved_row);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(ctx->ev[3], st));
+    if (labels) {
+        HIPCHK(hipMemsetAsync(labels, 0, (size_t)n * P * 4, st));
+        if (nfg > 0) hipLaunchKernelGGL(k_label_runs, dim3(nblocks(nfg)), dim3(256), 0, st, S, nfg, (const int32_t *)objlabel, labels);
+    }
+    HIPCHK(hipEventRecord(ctx->ev[4], st));
+    long long h_tot[2] = {0, 0};
+    if (n_saved > 0) {
+        hipLaunchKernelGGL(k_saved_geo, dim3(nblocks(n_saved)), dim3(256), 0, st, n_saved, (const int32_t *)saved_row, R, geo, sz);
+        hipLaunchKernelGGL(k_scan_sizes, dim3(1), dim3(64), 0, st, (const unsigned long long *)sz, n_saved,
+                           (long long *)ctx->crop_off.p, (long long *)ctx->bits_off.p);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(&h_tot[0], (long long *)ctx->crop_off.p + n_saved, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(&h_tot[1], (long long *)ctx->bits_off.p + n_saved, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        ENSURE(ctx->crops_raw, (size_t)h_tot[0]); ENSURE(ctx->crops_masked, (size_t)h_tot[0]); ENSURE(ctx->crops_mask, (size_t)h_tot[0]);
+        ENSURE(ctx->maskbits, (size_t)h_tot[1] * 4);
+        HIPCHK(hipMemsetAsync(ctx->sums.p, 0, (size_t)n_saved * PSEG_NSUMS * 8, st));
+        hipLaunchKernelGGL(k_build_masks, dim3(n_saved), dim3(256), 0, st, S, (const int32_t *)geo, (const long long *)ctx->bits_off.p,
+                           (const int32_t *)objflag, (uint32_t *)ctx->maskbits.p);
+        hipLaunchKernelGGL(k_crops_sums, dim3(n_saved), dim3(256), 0, st, S, (const int32_t *)geo, (const long long *)ctx->crop_off.p,
+                           (const long long *)ctx->bits_off.p, (const uint32_t *)ctx->maskbits.p, cleaned, raw,
+                           (uint8_t *)ctx->crops_raw.p, (uint8_t *)ctx->crops_masked.p, (uint8_t *)ctx->crops_mask.p,
+                           (long long *)ctx->sums.p);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipEventRecord(ctx->ev[5], st));
+    ctx->crop_bytes = h_tot[0];
+    ctx->n_saved = n_saved;
+
+    // ---- results to the host ----
+    int32_t *hrows = ctx->h_rows.as<int32_t>(rcap * 10);
+    int32_t *h_saved_row = ctx->h_saved_row.as<int32_t>(scap);
+    int64_t *h_crop_off = ctx->h_crop_off.as<int64_t>(scap + 1);
+    int64_t *h_sums = ctx->h_sums.as<int64_t>(scap * PSEG_NSUMS);
+    h_crop_off[0] = 0;
+    if (n_rows > 0) HIPCHK(hipMemcpyAsync(hrows, ctx->rows.p, rcap * 10 * 4, hipMemcpyDeviceToHost, st));
+    if (n_saved > 0) {
+        HIPCHK(hipMemcpyAsync(h_saved_row, saved_row, (size_t)n_saved * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(h_crop_off, ctx->crop_off.p, (size_t)(n_saved + 1) * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(h_sums, ctx->sums.p, (size_t)n_saved * PSEG_NSUMS * 8, hipMemcpyDeviceToHost, st));
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipEventElapsedTime(&ctx->ms[2], ctx->ev[2], ctx->ev[3]));
+    HIPCHK(hipEventElapsedTime(&ctx->ms[3], ctx->ev[3], ctx->ev[4]));
+    HIPCHK(hipEventElapsedTime(&ctx->ms[4], ctx->ev[4], ctx->ev[5]));
+
+    int32_t *h_fro = ctx->h_frame_row_offset.as<int32_t>(n + 1);
+    int32_t *h_fnc = ctx->h_frame_n_contours.as<int32_t>(n);
+    uint8_t *h_fv = ctx->h_frame_valid.as<uint8_t>(n);
+    double *h_mean = ctx->h_frame_mean.as<double>(n);
+    double *h_std = ctx->h_frame_std.as<double>(n);
+    for (int f = 0; f <= n; f++) h_fro[f] = (int32_t)h_rowbase[f];
+    for (int f = 0; f < n; f++) {
+        h_fnc[f] = (int32_t)h_ftot3[3 * f];
+        h_fv[f] = hvalid[f];
+        finish_meanstd(fs.data() + 4 * f + 2, (double)h_maskcnt, &h_mean[f], &h_std[f]);
+    }
+    double *h_area = ctx->h_area.as<double>(rcap);
+    uint8_t *h_s8 = ctx->h_saved8.as<uint8_t>(rcap);
+    double *h_props = ctx->h_props.as<double>(rcap * PSEG_NPROPS);
+    for (int i = 0; i < n_rows; i++) {
+        h_area[i] = 0.5 * (double)hrows[3 * rcap + i];
+        h_s8[i] = (uint8_t)hrows[8 * rcap + i];
+        for (int k = 0; k < PSEG_NPROPS; k++) h_props[(size_t)i * PSEG_NPROPS + k] = NAN;
+    }
+    for (int s = 0; s < n_saved; s++) {
+        int i = h_saved_row[s];
+        const int64_t *q = h_sums + (size_t)s * PSEG_NSUMS;
+        double *p = h_props + (size_t)i * PSEG_NPROPS;
+        const double w = hrows[6 * rcap + i], h = hrows[7 * rcap + i];
+        const double N = (double)q[0];
+        const double cr = q[1] / N, cc = q[2] / N;
+        const double mu20 = q[3] / N - cr * cr, mu02 = q[4] / N - cc * cc, mu11 = q[5] / N - cr * cc;
+        const double a = mu02, b = -mu11, c = mu20;       // inertia tensor [[a,b],[b,c]]
+        const double tr = 0.5 * (a + c), dt = sqrt(0.25 * (a - c) * (a - c) + b * b);
+        double l1 = tr + dt, l2 = tr - dt;
+        if (l1 < 0) l1 = 0;
+        if (l2 < 0) l2 = 0;
+        const double major = 4 * sqrt(l1), minor = 4 * sqrt(l2);
+        double orient = (a - c == 0) ? (b < 0 ? -M_PI / 4 : M_PI / 4) : 0.5 * atan2(-2 * b, c - a);
+        p[0] = w; p[1] = h; p[2] = 0; p[3] = 0;
+        p[5] = N;
+        p[8] = major; p[9] = minor; p[10] = cr; p[11] = cc;
+        p[13] = (double)q[6]; p[14] = (double)q[7]; p[15] = q[8] / N;
+        p[18] = major / minor;
+        p[19] = (double)(uint8_t)(q[7] - q[6]);
+        p[23] = orient / M_PI * 180 + 90;
+        p[24] = w * h;
+        p[25] = l1 == 0 ? 0 : sqrt(1 - l2 / l1);
+        p[26] = sqrt(4 * N / M_PI);
+        p[28] = N / (w * h);
+        p[29] = cc; p[30] = cr;
+    }
+    if (out) {
+        memset(out, 0, sizeof(*out));
+        out->n_frames = n; out->n_rows = n_rows; out->n_saved = n_saved; out->crop_bytes = ctx->crop_bytes;
+        out->frame_row_offset = h_fro; out->frame_n_contours = h_fnc; out->frame_valid = h_fv;
+        out->frame_mean = h_mean; out->frame_std = h_std;
+        out->row_frame = hrows; out->row_c = hrows + rcap; out->row_label = hrows + 2 * rcap; out->row_area = h_area;
+        out->row_x = hrows + 4 * rcap; out->row_y = hrows + 5 * rcap; out->row_w = hrows + 6 * rcap; out->row_h = hrows + 7 * rcap;
+        out->row_saved = h_s8; out->row_props = h_props; out->saved_row = h_saved_row; out->crop_offset = h_crop_off;
+        out->sums = h_sums;
+        out->crops_raw_dev = (const uint8_t *)ctx->crops_raw.p; out->crops_masked_dev = (const uint8_t *)ctx->crops_masked.p;
+        out->crops_mask_dev = (const uint8_t *)ctx->crops_mask.p;
+    }
+    return PSEG_OK;
+}
+
+extern "C" int pseg_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw, const uint8_t *mask, const uint8_t *valid,
+                           int n, int threshold, double min_area_to_segment, double min_area_to_save, int32_t *labels,
+                           pseg_table *out)
+{
+    int r = check_batch(ctx, n);
+    if (r) return r;
+    if (!cleaned) return fail(ctx, PSEG_ERR_ARG, "null cleaned pointer");
+    if (!raw) raw = cleaned;
+    size_t P = ctx->P;
+    unsigned nblk = nblocks(P / 8);
+    ENSURE(ctx->bits, (size_t)n * P / 8);
+    ENSURE(ctx->partials, (size_t)n * nblk * 4 * sizeof(uint32_t));
+    ENSURE(ctx->fsums, (size_t)n * 4 * sizeof(uint64_t));
+    ENSURE(ctx->valid_dev, (size_t)n);
+    HIPCHK(hipEventRecord(ctx->ev[6], ctx->stream));
+    if (valid) HIPCHK(hipMemcpyAsync(ctx->valid_dev.p, valid, n, hipMemcpyHostToDevice, ctx->stream));
+    else HIPCHK(hipMemsetAsync(ctx->valid_dev.p, 1, n, ctx->stream));
+    HIPCHK(hipEventRecord(ctx->ev[0], ctx->stream));
+    hipLaunchKernelGGL(k_threshold, dim3(nblk, n), dim3(256), 0, ctx->stream, cleaned, P, mask, threshold, (uint8_t *)ctx->bits.p,
+                       (uint32_t *)ctx->partials.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
+    hipLaunchKernelGGL(k_reduce_partials, dim3(n), dim3(256), 0, ctx->stream, (const uint32_t *)ctx->partials.p, (int)nblk,
+                       (unsigned long long)P, (unsigned long long *)ctx->fsums.p, (uint8_t *)ctx->valid_dev.p, 0, 2, 2);
+    HIPCHK(hipGetLastError());
+    r = run_detect(ctx, cleaned, raw, mask, n, min_area_to_segment, min_area_to_save, labels, out);
+    if (r) return r;
+    HIPCHK(hipEventRecord(ctx->ev[7], ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipEventElapsedTime(&ctx->ms[1], ctx->ev[0], ctx->ev[1]));
+    HIPCHK(hipEventElapsedTime(&ctx->ms[5], ctx->ev[6], ctx->ev[7]));
+    ctx->ms[0] = 0;
+    return PSEG_OK;
+}
+
+extern "C" int pseg_process(pseg_ctx *ctx, const uint8_t *frames, int n, int n_bg_imgs, const uint8_t *mask, int threshold,
+                            double min_area_to_segment, double min_area_to_save, uint8_t *cleaned, double *mean_std,
+                            uint8_t *valid, int32_t *labels, pseg_table *out)
+{
+    int r = check_batch(ctx, n);
+    if (r) return r;
+    if (!frames || !cleaned) return fail(ctx, PSEG_ERR_ARG, "null frame pointer");
+    HIPCHK(hipEventRecord(ctx->ev[6], ctx->stream));
+    r = run_bg(ctx, frames, n, n_bg_imgs, mask, threshold, cleaned);
+    if (r) return r;
+    r = run_detect(ctx, cleaned, cleaned, mask, n, min_area_to_segment, min_area_to_save, labels, out);
+    if (r) return r;
+    HIPCHK(hipEventRecord(ctx->ev[7], ctx->stream));
+    r = fetch_raw_stats(ctx, n, mean_std, valid);
+    if (r) return r;
+    HIPCHK(hipEventElapsedTime(&ctx->ms[0], ctx->ev[0], ctx->ev[1]));
+    HIPCHK(hipEventElapsedTime(&ctx->ms[5], ctx->ev[6], ctx->ev[7]));
+    ctx->ms[1] = 0;
+    return PSEG_OK;
+}
+
+extern "C" int pseg_fetch_crops(pseg_ctx *ctx, uint8_t *raw, uint8_t *masked, uint8_t *mask)
+{
+    if (!ctx) return PSEG_ERR_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    size_t nb = (size_t)ctx->crop_bytes;
+    if (nb == 0) return PSEG_OK;
+    if (raw) HIPCHK(hipMemcpyAsync(raw, ctx->crops_raw.p, nb, hipMemcpyDeviceToHost, ctx->stream));
+    if (masked) HIPCHK(hipMemcpyAsync(masked, ctx->crops_masked.p, nb, hipMemcpyDeviceToHost, ctx->stream));
+    if (mask) HIPCHK(hipMemcpyAsync(mask, ctx->crops_mask.p, nb, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return PSEG_OK;
+}
+
+// cv.circle(mask, (W/2, H/2), radius, 255, -1): midpoint circle, horizontal spans (detection.py:320-326)
+extern "C" int pseg_disk_mask(pseg_ctx *ctx, int radius, uint8_t *mask)
+{
+    if (!ctx || !mask || radius < 0) return PSEG_ERR_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    const int H = ctx->H, W = ctx->W, cx = H / 2, cy = W / 2;   // reference passes (shape[0]/2, shape[1]/2) as (x, y)
+    std::vector<int32_t> sp((size_t)2 * H);
+    for (int y = 0; y < H; y++) { sp[2 * y] = W; sp[2 * y + 1] = -1; }
+    auto span = [&](int y, int xa, int xb) {
+        if (y < 0 || y >= H) return;
+        if (xa < sp[2 * y]) sp[2 * y] = xa;
+        if (xb > sp[2 * y + 1]) sp[2 * y + 1] = xb;
+    };
+    int err = 0, dx = radius, dy = 0, plus = 1, minus = (radius << 1) - 1;
+    while (dx >= dy) {
+        span(cy - dy, cx - dx, cx + dx); span(cy + dy, cx - dx, cx + dx);
+        span(cy - dx, cx - dy, cx + dy); span(cy + dx, cx - dy, cx + dy);
+        dy++; err += plus; plus += 2;
+        int m = (err <= 0) - 1;
+        err -= minus & m; dx += m; minus -= m & 2;
+    }
+    ENSURE(ctx->rowspans, (size_t)2 * H * 4);
+    HIPCHK(hipMemcpyAsync(ctx->rowspans.p, sp.data(), (size_t)2 * H * 4, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_fill_spans, dim3(H), dim3(256), 0, ctx->stream, mask, H, W, (const int32_t *)ctx->rowspans.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return PSEG_OK;
+}
+
+extern "C" int pseg_synth_frames(pseg_ctx *ctx, int n, int frame0, uint64_t seed, const int32_t *objs, const int32_t *frame_obj_off,
+                                 uint8_t *out)
+{
+    if (!ctx || !out || !frame_obj_off || n < 1) return PSEG_ERR_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    int nobj = frame_obj_off[n];
+    DevBuf dobj, doff;
+    ENSURE(dobj, (size_t)(nobj > 0 ? nobj : 1) * 8 * 4);
+    ENSURE(doff, (size_t)(n + 1) * 4);
+    if (nobj > 0) HIPCHK(hipMemcpy(dobj.p, objs, (size_t)nobj * 8 * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(doff.p, frame_obj_off, (size_t)(n + 1) * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_synth, dim3(nblocks(ctx->P), n), dim3(256), 0, ctx->stream, out, ctx->H, ctx->W, frame0,
+                       (unsigned long long)seed, (const int32_t *)dobj.p, (const int32_t *)doff.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    hipFree(dobj.p); hipFree(doff.p);
+    return PSEG_OK;
+}

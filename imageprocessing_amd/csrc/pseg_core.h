@@ -1,0 +1,321 @@
+// pseg_core.h -- per-thread bodies of the sparse (run-based) segmentation kernels.
+//
+// Everything after the dense streaming kernels works on the 1-bit threshold plane: foreground
+// runs per row, union-find over runs (8-connected foreground, 4-connected background incl. the
+// zero padding the reference's findContours assumes), the enclosure tree (external component ->
+// hole -> nested component ...), and per-object integer accumulators.  The bodies are plain
+// functions of a thread index so that the HIP kernels in piscoseg.hip are one-line wrappers and
+// the test-only serial emulator (tests/emu) can run the identical logic on a CPU.
+//
+// Reference semantics restated:
+//   cv.findContours(RETR_EXTERNAL)      detection.py:204  -> external components = components
+//                                        adjacent to the frame-connected background
+//   cv.contourArea                      detection.py:208  -> Q4 + Q3/2 over 2x2 quads of the
+//                                        hole-filled object
+//   cv.boundingRect                     detection.py:212  -> extents of the component's runs
+//   cv.drawContours(FILLED)             detection.py:245  -> component + everything it encloses
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define PSEG_HD __host__ __device__ inline
+#else
+#define PSEG_HD inline
+#endif
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PSEG_ATOMIC_MIN(p, v) atomicMin((p), (v))
+#define PSEG_ATOMIC_MAX(p, v) atomicMax((p), (v))
+#define PSEG_ATOMIC_ADD(p, v) atomicAdd((p), (v))
+#define PSEG_POPC64(v) __popcll(v)
+#define PSEG_CTZ64(v) (__ffsll((unsigned long long)(v)) - 1)
+#else
+template <class T> static inline T pseg_amin(T *p, T v) { T o = *p; if (v < o) *p = v; return o; }
+template <class T> static inline T pseg_amax(T *p, T v) { T o = *p; if (v > o) *p = v; return o; }
+template <class T> static inline T pseg_aadd(T *p, T v) { T o = *p; *p = o + v; return o; }
+#define PSEG_ATOMIC_MIN(p, v) pseg_amin((p), (v))
+#define PSEG_ATOMIC_MAX(p, v) pseg_amax((p), (v))
+#define PSEG_ATOMIC_ADD(p, v) pseg_aadd((p), (v))
+#define PSEG_POPC64(v) __builtin_popcountll(v)
+#define PSEG_CTZ64(v) __builtin_ctzll(v)
+#endif
+
+// Device-resident state of one detection call (all pointers device memory).
+struct SegState {
+    int F, H, W, WW;                 // frames, rows, cols, 64-bit words per row
+    const uint64_t *bits;            // [F][H][WW] threshold plane, bit b of word w = pixel 64w+b
+    const uint8_t *valid;            // [F] 0 = corrupt frame (treated as empty)
+    uint32_t *rowcnt;                // [F*H] foreground runs per row
+    uint32_t *rowoff;                // [F*(H+1)] exclusive scan of rowcnt inside the frame
+    uint32_t *framebase;             // [F+1] exclusive scan of runs per frame
+    // per foreground run (global index r = framebase[f] + rowoff[f][y] + j)
+    uint32_t *run_x;                 // xs | xe << 16
+    uint32_t *run_fy;                // y | f << 16
+    int32_t *fg_parent;              // union-find, root = smallest (raster-first) run
+    int32_t *ext;                    // root run of the enclosing EXTERNAL component
+    // per background element (b = r + f*H + y for the gap left of run r; one extra per row)
+    int32_t *bg_parent;
+    int32_t *bg_left;                // foreground run immediately left of the gap, -1 for j = 0
+    // per object, indexed by its root run
+    int32_t *minx, *maxx, *miny, *maxy;
+    int32_t *area2;                  // 2*Q4 + Q3 = 2 * contourArea
+    int32_t *extrank, *keptrank, *savedrank;   // exclusive ranks inside the frame
+};
+
+PSEG_HD int seg_rowstart(const SegState &S, int f, int y) { return (int)(S.framebase[f] + S.rowoff[f * (S.H + 1) + y]); }
+PSEG_HD int seg_rowcount(const SegState &S, int f, int y) { return (int)(S.rowoff[f * (S.H + 1) + y + 1] - S.rowoff[f * (S.H + 1) + y]); }
+PSEG_HD int seg_bgbase(const SegState &S, int f, int y) { return seg_rowstart(S, f, y) + f * S.H + y; }
+PSEG_HD int run_xs(const SegState &S, int r) { return (int)(S.run_x[r] & 0xffffu); }
+PSEG_HD int run_xe(const SegState &S, int r) { return (int)(S.run_x[r] >> 16); }
+
+PSEG_HD uint64_t seg_starts(const SegState &S, size_t g, int w, uint64_t v)
+{
+    uint64_t prev = w > 0 ? (S.bits[g - 1] >> 63) : 0;
+    return v & ~((v << 1) | prev);
+}
+
+// ---- 1. count foreground runs per row (thread per 64-bit word) -------------------------------
+PSEG_HD void count_runs_body(const SegState &S, size_t g)
+{
+    int w = (int)(g % S.WW);
+    size_t fy = g / S.WW;
+    int f = (int)(fy / S.H);
+    if (!S.valid[f]) return;
+    uint64_t v = S.bits[g];
+    if (!v) return;
+    uint64_t st = seg_starts(S, g, w, v);
+    if (st) PSEG_ATOMIC_ADD(&S.rowcnt[fy], (uint32_t)PSEG_POPC64(st));
+}
+
+// ---- 2. write the runs (thread per word) ------------------------------------------------------
+PSEG_HD void fill_runs_body(const SegState &S, size_t g)
+{
+    int w = (int)(g % S.WW);
+    size_t fy = g / S.WW;
+    int f = (int)(fy / S.H), y = (int)(fy % S.H);
+    if (!S.valid[f]) return;
+    uint64_t v = S.bits[g];
+    if (!v) return;
+    uint64_t st = seg_starts(S, g, w, v);
+    if (!st) return;
+    int idx = seg_rowstart(S, f, y);
+    size_t g0 = g - w;
+    for (int k = 0; k < w; k++) {
+        uint64_t u = S.bits[g0 + k];
+        if (u) idx += PSEG_POPC64(seg_starts(S, g0 + k, k, u));
+    }
+    while (st) {
+        int s = PSEG_CTZ64(st);
+        st &= st - 1;
+        uint64_t t = ~(v >> s);                       // zeros mark the run's extent from bit s
+        int ones = t ? PSEG_CTZ64(t) : 64;
+        if (ones > 64 - s) ones = 64 - s;
+        int xe = 64 * w + s + ones - 1;
+        if (s + ones == 64) {                           // run continues into the next words
+            for (int k = w + 1; k < S.WW; k++) {
+                uint64_t u = S.bits[g0 + k];
+                if (u == ~0ull) { xe += 64; continue; }
+                xe += (~u) ? PSEG_CTZ64(~u) : 0;
+                break;
+            }
+        }
+        S.run_x[idx] = (uint32_t)(64 * w + s) | ((uint32_t)xe << 16);
+        S.run_fy[idx] = (uint32_t)y | ((uint32_t)f << 16);
+        idx++;
+    }
+}
+
+// ---- union-find (link the larger root under the smaller one) -------------------------------
+PSEG_HD int uf_find(const int32_t *parent, int a)
+{
+    int p = parent[a];
+    while (p != a) { a = p; p = parent[a]; }
+    return a;
+}
+PSEG_HD void uf_union(int32_t *parent, int a, int b)
+{
+    for (int guard = 0; guard < (1 << 30); guard++) {
+        a = uf_find(parent, a);
+        b = uf_find(parent, b);
+        if (a == b) return;
+        int hi = a > b ? a : b, lo = a > b ? b : a;
+        int old = PSEG_ATOMIC_MIN(&parent[hi], lo);
+        if (old == hi) return;
+        a = old; b = lo;
+    }
+}
+
+PSEG_HD void init_run_body(const SegState &S, int r)
+{
+    S.fg_parent[r] = r;
+    S.minx[r] = 0x7fffffff; S.miny[r] = 0x7fffffff; S.maxx[r] = -1; S.maxy[r] = -1;
+    S.area2[r] = 0;
+}
+PSEG_HD void init_bg_body(const SegState &S, int b) { S.bg_parent[b] = b; }
+
+// ---- 3. foreground unions, 8-connectivity (thread per run) -----------------------------------
+PSEG_HD void fg_union_body(const SegState &S, int r)
+{
+    int y = (int)(S.run_fy[r] & 0xffffu), f = (int)(S.run_fy[r] >> 16);
+    if (y == 0) return;
+    int p0 = seg_rowstart(S, f, y - 1), p1 = seg_rowstart(S, f, y);
+    if (p0 == p1) return;
+    int lo = run_xs(S, r) - 1, hi = run_xe(S, r) + 1;
+    int a = p0, b = p1;                                  // first q with xe_q >= lo
+    while (a < b) { int m = (a + b) >> 1; if (run_xe(S, m) >= lo) b = m; else a = m + 1; }
+    for (int q = a; q < p1 && run_xs(S, q) <= hi; q++) uf_union(S.fg_parent, r, q);
+}
+
+// ---- 4. background unions, 4-connectivity, frame padded with zeros ---------------------------
+// Element j of row (f,y) is the gap left of foreground run j (j = n is the gap after the last
+// run); gaps 0 and n reach the padding columns x = -1 and x = W.
+PSEG_HD void bg_union_elem(const SegState &S, int f, int y, int j)
+{
+    int rs = seg_rowstart(S, f, y), n = seg_rowcount(S, f, y);
+    int bb = rs + f * S.H + y, b = bb + j;
+    int a = j == 0 ? -1 : run_xe(S, rs + j - 1) + 1;
+    int e = j == n ? S.W : run_xs(S, rs + j) - 1;
+    S.bg_left[b] = j == 0 ? -1 : rs + j - 1;
+    if (j == n && n > 0) uf_union(S.bg_parent, b, bb);
+    if ((y == 0 || y == S.H - 1) && j > 0) uf_union(S.bg_parent, b, bb);
+    if (y == 0) return;
+    int ps = seg_rowstart(S, f, y - 1), pn = rs - ps, pb = ps + f * S.H + (y - 1);
+    // first gap j' of the previous row whose right end (xs_{j'} - 1, or W for j' = pn) >= a
+    int lo = 0, hi = pn;
+    while (lo < hi) { int m = (lo + hi) >> 1; if (run_xs(S, ps + m) >= a + 1) hi = m; else lo = m + 1; }
+    for (int q = lo; q <= pn; q++) {
+        int qa = q == 0 ? -1 : run_xe(S, ps + q - 1) + 1;
+        if (qa > e) break;
+        uf_union(S.bg_parent, b, pb + q);
+    }
+}
+// thread t < nfg : gap left of run t ; thread t >= nfg : trailing gap of row (t - nfg)
+PSEG_HD void bg_union_body(const SegState &S, int t, int nfg)
+{
+    if (t < nfg) {
+        int y = (int)(S.run_fy[t] & 0xffffu), f = (int)(S.run_fy[t] >> 16);
+        bg_union_elem(S, f, y, t - seg_rowstart(S, f, y));
+    } else {
+        int fy = t - nfg, f = fy / S.H, y = fy % S.H;
+        bg_union_elem(S, f, y, seg_rowcount(S, f, y));
+    }
+}
+
+PSEG_HD void flatten_body(int32_t *parent, int i) { parent[i] = uf_find(parent, i); }
+
+// ---- 5. enclosure tree: external ancestor of every run ---------------------------------------
+PSEG_HD int seg_b0(const SegState &S, int f) { return (int)S.framebase[f] + f * S.H; }
+PSEG_HD void resolve_ext_body(const SegState &S, int r)
+{
+    int R = S.fg_parent[r];
+    for (int guard = 0; guard < 65536; guard++) {
+        int y = (int)(S.run_fy[R] & 0xffffu), f = (int)(S.run_fy[R] >> 16);
+        int hb = S.bg_parent[R + f * S.H + y];           // background around R's raster-first pixel
+        if (hb == seg_b0(S, f)) break;                   // frame-connected: R is external
+        R = S.fg_parent[S.bg_left[hb]];                  // component that owns the hole
+    }
+    S.ext[r] = R;
+}
+// object id of a background element: -1 = outside every object
+PSEG_HD int bg_gid(const SegState &S, int f, int b)
+{
+    int hb = S.bg_parent[b];
+    if (hb == seg_b0(S, f)) return -1;
+    return S.ext[S.bg_left[hb]];
+}
+
+// ---- 6. bounding boxes (thread per run) -------------------------------------------------------
+PSEG_HD void bbox_body(const SegState &S, int r)
+{
+    int E = S.ext[r];
+    int y = (int)(S.run_fy[r] & 0xffffu);
+    PSEG_ATOMIC_MIN(&S.minx[E], run_xs(S, r));
+    PSEG_ATOMIC_MAX(&S.maxx[E], run_xe(S, r));
+    PSEG_ATOMIC_MIN(&S.miny[E], y);
+    PSEG_ATOMIC_MAX(&S.maxy[E], y);
+}
+
+// ---- spans of the hole-filled objects in one row ------------------------------------------------
+struct SpanIter { int rs, n, bb, f, e; };
+PSEG_HD void span_begin(const SegState &S, SpanIter &it, int f, int y)
+{
+    it.rs = seg_rowstart(S, f, y); it.n = seg_rowcount(S, f, y);
+    it.bb = it.rs + f * S.H + y; it.f = f; it.e = 1;    // element 0 is always outside
+}
+PSEG_HD int span_elem_id(const SegState &S, const SpanIter &it, int e)
+{
+    if (e & 1) return S.ext[it.rs + (e >> 1)];
+    return bg_gid(S, it.f, it.bb + (e >> 1));
+}
+PSEG_HD bool span_next(const SegState &S, SpanIter &it, int &id, int &xs, int &xe)
+{
+    const int last = 2 * it.n;                          // element 2n is always outside
+    while (it.e < last) {
+        int cid = span_elem_id(S, it, it.e);
+        if (cid < 0) { it.e++; continue; }
+        int e = it.e;
+        xs = (e & 1) ? run_xs(S, it.rs + (e >> 1)) : run_xe(S, it.rs + (e >> 1) - 1) + 1;
+        do {
+            e = it.e;
+            xe = (e & 1) ? run_xe(S, it.rs + (e >> 1)) : run_xs(S, it.rs + (e >> 1)) - 1;
+            it.e++;
+        } while (it.e < last && span_elem_id(S, it, it.e) == cid);
+        id = cid;
+        return true;
+    }
+    return false;
+}
+
+// ---- 7. contour area from 2x2 quads of the filled object (thread per row pair) ----------------
+PSEG_HD void area_body(const SegState &S, int fy)
+{
+    int f = fy / S.H, y = fy % S.H;
+    if (y + 1 >= S.H) return;
+    if (seg_rowcount(S, f, y) == 0 || seg_rowcount(S, f, y + 1) == 0) return;
+    SpanIter ia, ib;
+    span_begin(S, ia, f, y);
+    span_begin(S, ib, f, y + 1);
+    int ida, a, b, idb, c, d;
+    bool ha = span_next(S, ia, ida, a, b), hb = span_next(S, ib, idb, c, d);
+    while (ha && hb) {
+        if (b < c) { ha = span_next(S, ia, ida, a, b); continue; }
+        if (d < a) { hb = span_next(S, ib, idb, c, d); continue; }
+        if (ida == idb) {
+            int lo = a > c ? a : c, hi = b < d ? b : d;
+            int q4 = hi - lo;                            // columns x with x, x+1 in both spans
+            int q3 = (a <= c - 1 && c <= b) + (a <= d && d + 1 <= b) + (c <= a - 1 && a <= d) + (c <= b && b + 1 <= d);
+            int add = 2 * (q4 > 0 ? q4 : 0) + q3;
+            if (add) PSEG_ATOMIC_ADD(&S.area2[ida], add);
+        }
+        if (b < d) ha = span_next(S, ia, ida, a, b);
+        else hb = span_next(S, ib, idb, c, d);
+    }
+}
+
+// classification of a run as the root of an external component
+PSEG_HD bool is_ext_root(const SegState &S, int r) { return S.fg_parent[r] == r && S.ext[r] == r; }
+
+// ---- 8. one 32-pixel word of the cumulative filled mask window of a saved object ---------------
+// Window row y, columns [x0, x1] (x1 - x0 <= 31).  A pixel is set iff it lies in the hole-filled region
+// of a SAVED object (objflag & 2) iterated at or before the owner (root index >= root):
+// detection.py:206,245-246 -- the frame mask accumulates over the object loop.
+PSEG_HD uint32_t mask_word_body(const SegState &S, const int32_t *objflag, int f, int y, int x0, int x1, int root)
+{
+    int rs = seg_rowstart(S, f, y), n = seg_rowcount(S, f, y), bb = rs + f * S.H + y;
+    int lo = 0, hi = n;                                  // first run j with xe >= x0
+    while (lo < hi) { int m = (lo + hi) >> 1; if (run_xe(S, rs + m) >= x0) hi = m; else lo = m + 1; }
+    uint32_t bitsv = 0;
+    for (int e = 2 * lo; e <= 2 * n; e++) {              // gap before run lo, run lo, gap, ...
+        int j = e >> 1, xs, xe, id;
+        if (e & 1) { xs = run_xs(S, rs + j); xe = run_xe(S, rs + j); }
+        else { xs = j == 0 ? -1 : run_xe(S, rs + j - 1) + 1; xe = j == n ? S.W : run_xs(S, rs + j) - 1; }
+        if (xs > x1) break;
+        if (xe < x0) continue;
+        id = (e & 1) ? S.ext[rs + j] : ((j == 0 || j == n) ? -1 : bg_gid(S, f, bb + j));
+        if (id < 0 || id < root || !(objflag[id] & 2)) continue;
+        int a = xs > x0 ? xs : x0, b = xe < x1 ? xe : x1;
+        uint32_t m = (b - a == 31) ? 0xffffffffu : (((1u << (b - a + 1)) - 1u) << (a - x0));
+        bitsv |= m;
+    }
+    return bitsv;
+}

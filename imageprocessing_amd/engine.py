@@ -1,0 +1,194 @@
+"""Thin Python face of the C ABI: device tensors in, object tables out.  torch is used for
+device memory only (``tensor.data_ptr()``); all arithmetic happens in libpiscoseg.so."""
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _lib
+
+PROP_KEYS = [
+    "width", "height", "bx", "by", "circ.", "area_exc", "area_rprops", "%area", "major", "minor",
+    "centroid_y", "centroid_x", "convex_area", "min_intensity", "max_intensity", "mean_intensity",
+    "intden", "perim.", "elongation", "range", "perimareaexc", "perimmajor", "circex", "angle",
+    "bounding_box_area", "eccentricity", "equivalent_diameter", "euler_number", "extent",
+    "local_centroid_col", "local_centroid_row", "solidity",
+]
+
+
+# columns the device does not produce yet (NaN in the table): SURVEY.md 8(f) N1
+PENDING_PROPS = {"circ.", "area_rprops", "%area", "convex_area", "intden", "perim.", "perimareaexc", "perimmajor",
+                 "circex", "euler_number", "solidity"}
+
+
+class PsegError(RuntimeError):
+    pass
+
+
+def _np(ptr, n, dtype):
+    if n <= 0:
+        return np.zeros(0, dtype)
+    return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dtype, copy=True)
+
+
+@dataclass
+class ObjectTable:
+    """Host copy of pseg_table (include/piscoseg.h); rows ordered (frame, c) like the reference's
+    per-frame CSV (detection.py:265,271)."""
+    n_frames: int
+    frame_row_offset: np.ndarray
+    frame_n_contours: np.ndarray
+    frame_valid: np.ndarray
+    frame_mean: np.ndarray
+    frame_std: np.ndarray
+    frame: np.ndarray
+    c: np.ndarray
+    label: np.ndarray
+    area: np.ndarray
+    x: np.ndarray
+    y: np.ndarray
+    w: np.ndarray
+    h: np.ndarray
+    saved: np.ndarray
+    props: np.ndarray
+    saved_row: np.ndarray
+    crop_offset: np.ndarray
+    sums: np.ndarray
+    crop_bytes: int
+    crops: dict = field(default_factory=dict)     # 'raw' / 'masked' / 'mask' packed uint8 planes (host), optional
+
+    @property
+    def n_rows(self):
+        return len(self.frame)
+
+    def crop(self, s, plane="masked"):
+        """h x w uint8 crop of saved object s from a fetched plane."""
+        i = self.saved_row[s]
+        a = self.crop_offset[s]
+        return self.crops[plane][a:a + self.h[i] * self.w[i]].reshape(self.h[i], self.w[i])
+
+
+class Segmenter:
+    """One context per GPU / Python thread.  Mirrors the stage split of the reference:
+    ``bgcorrect`` = bg_correction.correct_img over a batch, ``detect`` = detection.detect_on_img over a
+    batch, ``process`` = both fused (segmenter.py:241,254 without deconvolution)."""
+
+    def __init__(self, H=2560, W=2560, max_frames=400, device=0):
+        self.L = _lib.load()
+        self.H, self.W, self.max_frames, self.device = H, W, max_frames, device
+        h = C.c_void_p()
+        rc = self.L.pseg_create(device, H, W, max_frames, C.byref(h))
+        if rc != 0:
+            raise PsegError(f"pseg_create failed with code {rc} (no usable HIP device?)")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.pseg_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise PsegError(f"libpiscoseg error {rc}: {self.L.pseg_last_error(self.h).decode()}")
+
+    def _check_frames(self, t, n=None, dtype=None):
+        import torch
+        dtype = dtype or torch.uint8
+        if not (t.is_cuda and t.dtype == dtype and t.is_contiguous()):
+            raise PsegError("expected a contiguous CUDA tensor of dtype %s" % dtype)
+        if t.shape[-2:] != (self.H, self.W) or (n is not None and t.shape[0] != n):
+            raise PsegError(f"bad tensor shape {tuple(t.shape)}")
+
+    def last_ms(self, which):
+        return float(self.L.pseg_last_ms(self.h, which))
+
+    def disk_mask(self, radius):
+        import torch
+        m = torch.empty((self.H, self.W), dtype=torch.uint8, device=f"cuda:{self.device}")
+        self._chk(self.L.pseg_disk_mask(self.h, int(radius), m.data_ptr()))
+        return m
+
+    def bgcorrect(self, frames, n_bg_imgs=6, cleaned=None):
+        import torch
+        n = frames.shape[0]
+        self._check_frames(frames)
+        if cleaned is None:
+            cleaned = torch.empty_like(frames)
+        self._check_frames(cleaned, n)
+        ms = np.zeros((n, 2), np.float64)
+        valid = np.zeros(n, np.uint8)
+        torch.cuda.current_stream(frames.device).synchronize()
+        self._chk(self.L.pseg_bgcorrect(self.h, frames.data_ptr(), n, n_bg_imgs, cleaned.data_ptr(), ms.ctypes.data, valid.ctypes.data))
+        return cleaned, ms, valid
+
+    def _table(self, t, fetch_crops):
+        n, nr, ns = t.n_frames, t.n_rows, t.n_saved
+        tab = ObjectTable(
+            n_frames=n,
+            frame_row_offset=_np(t.frame_row_offset, n + 1, np.int32), frame_n_contours=_np(t.frame_n_contours, n, np.int32),
+            frame_valid=_np(t.frame_valid, n, np.uint8), frame_mean=_np(t.frame_mean, n, np.float64), frame_std=_np(t.frame_std, n, np.float64),
+            frame=_np(t.row_frame, nr, np.int32), c=_np(t.row_c, nr, np.int32), label=_np(t.row_label, nr, np.int32),
+            area=_np(t.row_area, nr, np.float64), x=_np(t.row_x, nr, np.int32), y=_np(t.row_y, nr, np.int32),
+            w=_np(t.row_w, nr, np.int32), h=_np(t.row_h, nr, np.int32), saved=_np(t.row_saved, nr, np.uint8),
+            props=_np(t.row_props, nr * _lib.NPROPS, np.float64).reshape(nr, _lib.NPROPS),
+            saved_row=_np(t.saved_row, ns, np.int32), crop_offset=_np(t.crop_offset, ns + 1, np.int64),
+            sums=_np(t.sums, ns * _lib.NSUMS, np.int64).reshape(ns, _lib.NSUMS), crop_bytes=int(t.crop_bytes))
+        if fetch_crops:
+            planes = {k: np.empty(max(tab.crop_bytes, 1), np.uint8) for k in ("raw", "masked", "mask")}
+            self._chk(self.L.pseg_fetch_crops(self.h, planes["raw"].ctypes.data, planes["masked"].ctypes.data, planes["mask"].ctypes.data))
+            tab.crops = {k: v[:tab.crop_bytes] for k, v in planes.items()}
+        return tab
+
+    def detect(self, cleaned, raw=None, mask=None, valid=None, threshold=10, min_area_to_segment=10.0,
+               min_area_to_save=400.0, labels=None, fetch_crops=False):
+        import torch
+        n = cleaned.shape[0]
+        self._check_frames(cleaned)
+        if raw is not None:
+            self._check_frames(raw, n)
+        if labels is not None:
+            self._check_frames(labels, n, torch.int32)
+        v = None if valid is None else np.ascontiguousarray(valid, dtype=np.uint8)
+        t = _lib.Table()
+        torch.cuda.current_stream(cleaned.device).synchronize()
+        self._chk(self.L.pseg_detect(self.h, cleaned.data_ptr(), None if raw is None else raw.data_ptr(),
+                                     None if mask is None else mask.data_ptr(), None if v is None else v.ctypes.data,
+                                     n, int(threshold), float(min_area_to_segment), float(min_area_to_save),
+                                     None if labels is None else labels.data_ptr(), C.byref(t)))
+        return self._table(t, fetch_crops)
+
+    def process(self, frames, n_bg_imgs=6, mask=None, threshold=10, min_area_to_segment=10.0, min_area_to_save=400.0,
+                cleaned=None, labels=None, fetch_crops=False, want_table=True):
+        import torch
+        n = frames.shape[0]
+        self._check_frames(frames)
+        if cleaned is None:
+            cleaned = torch.empty_like(frames)
+        self._check_frames(cleaned, n)
+        if labels is not None:
+            self._check_frames(labels, n, torch.int32)
+        ms = np.zeros((n, 2), np.float64)
+        valid = np.zeros(n, np.uint8)
+        t = _lib.Table()
+        torch.cuda.current_stream(frames.device).synchronize()
+        self._chk(self.L.pseg_process(self.h, frames.data_ptr(), n, n_bg_imgs, None if mask is None else mask.data_ptr(),
+                                      int(threshold), float(min_area_to_segment), float(min_area_to_save), cleaned.data_ptr(),
+                                      ms.ctypes.data, valid.ctypes.data, None if labels is None else labels.data_ptr(), C.byref(t)))
+        tab = self._table(t, fetch_crops) if want_table else None
+        return cleaned, ms, valid, tab
+
+    def synth_frames(self, n, seed, objs, frame_obj_off, frame0=0, out=None):
+        import torch
+        if out is None:
+            out = torch.empty((n, self.H, self.W), dtype=torch.uint8, device=f"cuda:{self.device}")
+        objs = np.ascontiguousarray(objs, dtype=np.int32).reshape(-1, 8)
+        off = np.ascontiguousarray(frame_obj_off, dtype=np.int32)
+        assert off.shape[0] == n + 1 and off[-1] == objs.shape[0]
+        self._chk(self.L.pseg_synth_frames(self.h, n, frame0, int(seed), objs.ctypes.data, off.ctypes.data, out.data_ptr()))
+        return out

@@ -1,0 +1,124 @@
+/*
+ * piscoseg.h -- C ABI of libpiscoseg.so, the MI355X (gfx950) implementation of the hot path of
+ * fannz00/ImageProcessing: background correction (bg_correction.py) -> threshold -> external
+ * objects -> per-object area / bbox / crops / region-property sums (detection.py).
+ *
+ * The reference is pure Python and has no FFI; the entry points below are what a ctypes binding
+ * placed inside the reference's own functions would call (INTEGRATION.md shows the stubs).  Each
+ * declaration cites the reference code it replaces (paths are /root/reference/...).
+ *
+ * Conventions: every function returns 0 on success and a negative code on failure (never
+ * aborts; the reference's convention is "print and carry on").  pseg_last_error() gives the text.
+ * Pointers marked [dev] are device pointers on the context's GPU (e.g. torch.Tensor.data_ptr()),
+ * [host] are host pointers.  Frames are row-major uint8 [n][H][W]; W must be a multiple of 64.
+ * A context is not re-entrant: one call at a time per context (one context per Python thread/GPU).
+ */
+#ifndef PISCOSEG_H
+#define PISCOSEG_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pseg_ctx pseg_ctx;
+
+#define PSEG_OK 0
+#define PSEG_ERR_ARG (-1)
+#define PSEG_ERR_HIP (-2)
+#define PSEG_ERR_CAPACITY (-3)
+#define PSEG_ERR_NODEVICE (-4)
+
+#define PSEG_NPROPS 32 /* columns 13..44 of the reference's CSV row, detection.py:84-152 */
+#define PSEG_NSUMS 24  /* integer sums per saved object, see pseg_table.sums */
+
+/* Result of one detection call.  All arrays are host memory owned by the context and stay valid
+ * until the next call on that context.  Row i describes one kept object (contourArea >=
+ * min_area_to_segment); rows are ordered by (frame, c) exactly like the reference's per-frame CSV
+ * (detection.py:222-273).  Replaces: the crop_data list of detect_on_img (detection.py:220,265,271). */
+typedef struct pseg_table {
+    int32_t n_frames;
+    int32_t n_rows;                   /* kept objects over all frames                               */
+    int32_t n_saved;                  /* rows with contourArea > min_area_to_save                   */
+    int64_t crop_bytes;               /* total bytes of one packed crop plane (sum of w*h, saved)   */
+    const int32_t *frame_row_offset;  /* [n_frames+1] rows of frame f = [off[f], off[f+1])          */
+    const int32_t *frame_n_contours;  /* [n_frames]  external contours before the area filters      */
+    const uint8_t *frame_valid;       /* [n_frames]  0 = corrupt frame (raw std <= 2), no rows      */
+    const double *frame_mean;         /* [n_frames]  mean of corrected inside the mask (CSV col 5)  */
+    const double *frame_std;          /* [n_frames]  std  of corrected inside the mask (CSV col 6)  */
+    const int32_t *row_frame;         /* [n_rows]                                                   */
+    const int32_t *row_c;             /* [n_rows] object index c (CSV col 1, file name suffix)      */
+    const int32_t *row_label;         /* [n_rows] 1-based OpenCV contour index = label-map value    */
+    const double *row_area;           /* [n_rows] cv.contourArea (CSV col 7)                        */
+    const int32_t *row_x, *row_y, *row_w, *row_h; /* cv.boundingRect, top-left + size              */
+    const uint8_t *row_saved;         /* [n_rows] 1 if contourArea > min_area_to_save (CSV col 12)  */
+    const double *row_props;          /* [n_rows*32] regionprops columns, NaN for unsaved rows      */
+    const int32_t *saved_row;         /* [n_saved] row index of saved object s                      */
+    const int64_t *crop_offset;       /* [n_saved+1] byte offset of object s in each crop plane     */
+    const int64_t *sums;              /* [n_saved*PSEG_NSUMS] exact integer sums behind row_props   */
+    /* packed crops on the device, row-major h*w per saved object at crop_offset[s]:              */
+    const uint8_t *crops_raw_dev;     /* raw_bg_corr[y:y+h, x:x+w]          (Crops/,  detection.py:244) */
+    const uint8_t *crops_masked_dev;  /* where(c_mask==255, crop, 255)      (Deconv_crops/, :247)      */
+    const uint8_t *crops_mask_dev;    /* cumulative filled mask window      (Masks/,  :245-246)        */
+} pseg_table;
+
+/* Create / destroy a context bound to one GPU.  max_frames bounds n of every later call. */
+int pseg_create(int device, int H, int W, int max_frames, pseg_ctx **out);
+int pseg_destroy(pseg_ctx *ctx);
+const char *pseg_last_error(const pseg_ctx *ctx);
+/* Run the context's work on an existing HIP stream (hipStream_t) instead of its own. */
+int pseg_set_stream(pseg_ctx *ctx, void *hip_stream);
+
+/* Background correction of one batch.  Replaces correct_img for every index of the batch
+ * (bg_correction.py:41-90; driven by run_bg_correction :93-127):
+ *   mean/std of the raw frame (:69-70), gate std > 2 (:71), window start (:72),
+ *   bg = max_k min(I[s+k], I[s+k+1]) over 2*n_bg_imgs frames (:74-78), cleaned = 255-|img-bg| (:80-81).
+ * frames [dev] u8[n][H][W]; cleaned [dev] u8[n][H][W] (contents of corrupt frames unspecified);
+ * mean_std [host] double[n][2]; valid [host] u8[n].  6 <= n_bg_imgs*... : needs n >= n_bg_imgs
+ * (the reference raises IndexError below that). */
+int pseg_bgcorrect(pseg_ctx *ctx, const uint8_t *frames, int n, int n_bg_imgs, uint8_t *cleaned,
+                   double *mean_std, uint8_t *valid);
+
+/* Detection on one batch of background-corrected frames.  Replaces detect_on_img for every
+ * frame (detection.py:162-297) minus PNG/CSV I/O:
+ *   corrected = 255 - cleaned (:178); mean/std inside mask == 255 and zero outside (:185-188);
+ *   thresh = corrected > threshold (:195-202); external contours in OpenCV order (:204);
+ *   contourArea / boundingRect (:208-216); area filters (:223,235); cumulative FILLED mask,
+ *   three crops (:243-247); sums for the 32 region properties (:75-159).
+ * cleaned [dev] u8[n][H][W]; raw [dev] the bg_corr image the Crops/ plane is cut from (may equal
+ * cleaned); mask [dev] u8[H][W] or NULL (settings.mask_img False); valid [host] u8[n] or NULL;
+ * labels [dev] int32[n][H][W] or NULL: k on the foreground pixels of the component of contour k
+ * (1-based, OpenCV order), 0 elsewhere. */
+int pseg_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw, const uint8_t *mask,
+                const uint8_t *valid, int n, int threshold, double min_area_to_segment,
+                double min_area_to_save, int32_t *labels, pseg_table *out);
+
+/* Fused hot path: pseg_bgcorrect + pseg_detect with the threshold plane and the masked sums
+ * produced inside the background kernel (no second pass over cleaned).  Same outputs as the two
+ * calls in sequence with raw == cleaned (the reference without deconvolution, segmenter.py:248-249). */
+int pseg_process(pseg_ctx *ctx, const uint8_t *frames, int n, int n_bg_imgs, const uint8_t *mask,
+                 int threshold, double min_area_to_segment, double min_area_to_save,
+                 uint8_t *cleaned, double *mean_std, uint8_t *valid, int32_t *labels, pseg_table *out);
+
+/* Copy the three packed crop planes of the last detection to host buffers of crop_bytes each
+ * (any may be NULL).  Replaces the arrays handed to cv.imwrite (detection.py:251-253). */
+int pseg_fetch_crops(pseg_ctx *ctx, uint8_t *raw, uint8_t *masked, uint8_t *mask);
+
+/* cv.circle(mask, (W/2, H/2), radius, 255, -1) on the device (detection.py:315-326). mask [dev] u8[H][W]. */
+int pseg_disk_mask(pseg_ctx *ctx, int radius, uint8_t *mask);
+
+/* Synthetic PISCO-like frames rendered on the device (bench / tests; no counterpart in the
+ * reference).  objs [host] int32[n_obj][8] = cx,cy,a,b,cosQ12,sinQ12,contrast,kind;
+ * frame_obj_off [host] int32[n+1]; out [dev] u8[n][H][W]. */
+int pseg_synth_frames(pseg_ctx *ctx, int n, int frame0, uint64_t seed, const int32_t *objs,
+                      const int32_t *frame_obj_off, uint8_t *out);
+
+/* Duration in milliseconds of the named kernel group of the last call, measured with HIP events on the
+ * context's stream: 0 = background kernel, 1 = threshold, 2 = sparse labelling chain,
+ * 3 = label-map write, 4 = masks + crops + sums, 5 = whole call. */
+float pseg_last_ms(const pseg_ctx *ctx, int which);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

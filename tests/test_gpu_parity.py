@@ -1,0 +1,96 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on identical inputs.
+Integer outputs bit-exact, floats within 1e-5 relative (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+def _stack(n, H, W, seed, **kw):
+    from imageprocessing_amd import synth
+    cfg = dict(synth.CONFIGS["pisco"])
+    cfg.update(kw)
+    objs, off = synth.make_objects(n, H, W, seed, **cfg)
+    return synth.render(n, H, W, seed, objs, off), objs, off
+
+
+def test_synth_device_matches_numpy(gpu_seg_factory):
+    H = W = 256
+    seg = gpu_seg_factory(H, W)
+    stack, objs, off = _stack(5, H, W, 7, per_frame=12, dmin=20, dmax=400)
+    dev = seg.synth_frames(5, 7, objs, off).cpu().numpy()
+    assert np.array_equal(dev, stack)
+
+
+@pytest.mark.parametrize("n", [6, 9, 12, 13, 30])
+def test_bgcorrect_parity(gpu_seg_factory, n):
+    import torch
+    H = W = 128
+    seg = gpu_seg_factory(H, W)
+    rng = np.random.default_rng(n)
+    stack = rng.integers(0, 256, (n, H, W), dtype=np.uint8)
+    stack[n // 2] = 77                      # constant frame: std = 0 -> corrupt
+    stack[n - 1] = (stack[n - 1] % 5) + 100   # std ~1.4 <= 2 -> corrupt
+    items = helpers.oracle_bgcorrect(stack)
+    cleaned, ms, valid = seg.bgcorrect(torch.from_numpy(stack).cuda())
+    cleaned = cleaned.cpu().numpy()
+    for i, it in enumerate(items):
+        np.testing.assert_allclose(ms[i], it[2], rtol=1e-9, atol=1e-9)
+        if isinstance(it[1], list):
+            assert valid[i] == 0
+        else:
+            assert valid[i] == 1
+            assert np.array_equal(cleaned[i], it[1]), f"frame {i}"
+
+
+@pytest.mark.parametrize("H,W,n,seed,kw", [
+    (256, 256, 14, 1, dict(per_frame=10, dmin=40, dmax=700)),
+    (512, 512, 13, 2, dict(per_frame=25, dmin=20, dmax=500, ring_frac=0.5)),
+    (256, 320, 12, 3, dict(per_frame=120, dmin=30, dmax=500)),
+])
+def test_process_parity(gpu_seg_factory, H, W, n, seed, kw):
+    import torch
+    seg = gpu_seg_factory(H, W)
+    stack, _, _ = _stack(n, H, W, seed, **kw)
+    stack[3] = 100                          # corrupt frame inside the batch
+    mask = helpers.make_disk(H, W, int(0.47 * min(H, W)))
+    items = helpers.oracle_bgcorrect(stack)
+    dets = helpers.oracle_detect(items, mask)
+    labels = torch.empty((n, H, W), dtype=torch.int32, device="cuda")
+    cleaned, ms, valid, tab = seg.process(torch.from_numpy(stack).cuda(), mask=torch.from_numpy(mask).cuda(),
+                                          labels=labels, fetch_crops=True)
+    assert tab.n_rows > 0 and tab.saved.sum() > 0
+    cl = cleaned.cpu().numpy()
+    for i, it in enumerate(items):
+        if not isinstance(it[1], list):
+            assert np.array_equal(cl[i], it[1])
+    helpers.compare_table(tab, dets, H, W, labels=labels.cpu().numpy())
+    # the two-call form gives the same table
+    tab2 = seg.detect(cleaned, raw=cleaned, mask=torch.from_numpy(mask).cuda(), valid=valid, fetch_crops=True)
+    helpers.compare_table(tab2, dets, H, W)
+
+
+def test_detect_noise_images(gpu_seg_factory):
+    """Dense random binary images: stresses nesting, pinches, spurs and the cumulative mask."""
+    import torch
+    H, W, n = 64, 128, 24
+    seg = gpu_seg_factory(H, W)
+    rng = np.random.default_rng(5)
+    cleaned = np.full((n, H, W), 255, np.uint8)
+    for f in range(n):
+        p = [0.2, 0.4, 0.5, 0.6, 0.7, 0.85][f % 6]
+        cleaned[f][rng.random((H, W)) < p] = rng.integers(0, 240, 1, dtype=np.uint8)[0]
+    items = [(cleaned[f], cleaned[f], [100.0, 50.0], f"n_{f:03d}.png") for f in range(n)]
+    dets = helpers.oracle_detect(items, None, min_area_to_segment=2, min_area_to_save=20, mask_img=False)
+    labels = torch.empty((n, H, W), dtype=torch.int32, device="cuda")
+    tab = seg.detect(torch.from_numpy(cleaned).cuda(), min_area_to_segment=2, min_area_to_save=20, labels=labels,
+                     fetch_crops=True)
+    helpers.compare_table(tab, dets, H, W, labels=labels.cpu().numpy())
+
+
+def test_disk_mask(gpu_seg_factory):
+    for H, W, r in [(256, 256, 120), (128, 128, 70), (64, 64, 10)]:
+        seg = gpu_seg_factory(H, W)
+        assert np.array_equal(seg.disk_mask(r).cpu().numpy(), helpers.make_disk(H, W, r))
