@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path (BASELINE.json): frames/s on 2560x2560 uint8 PISCO-like stacks.
+
+One "step" = one pass of the fused hot path (background correction -> threshold -> external
+objects -> area/bbox/label map -> crops + property sums) over one reference batch of 200 frames
+(segmenter.py:209) already resident in HBM.  The N=1 workload is BASELINE.json configs[1]: a
+2000-frame stack (10 batches), ~50 objects/frame.  With N>1 every rank runs its own 10 batches
+(weak scaling; batches are independent in the reference) and the object tables are gathered to
+rank 0 over RCCL inside the timed region.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel group, timed with HIP events
+on the library's stream; `cpu_baseline` is the CPU oracle (a port of the reference's arithmetic) on
+a bounded sample of the same frames on the host cores of this box.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+H = W = 2560
+P = H * W
+BATCH = 200
+HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: 8.0 TB/s spec peak
+PATH_BYTES_PER_FRAME = 6 * P               # raw read + cleaned write + int32 label write
+# algorithmic HBM bytes per frame of each kernel group (DESIGN.md "Kernels and rooflines")
+GROUP_BYTES = {
+    "bg_correct": 2 * P + P // 8,          # read raw once, write cleaned once, write the 1-bit plane
+    "label_map": 4 * P,                    # int32 label map written once
+}
+GROUP_NAMES = {0: "bg_correct", 2: "sparse_labelling", 3: "label_map", 4: "crops_props"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batches", type=int, default=10, help="distinct 200-frame batches resident per rank")
+    ap.add_argument("--workload", default="pisco", choices=["pisco", "uvp5_dense"])
+    ap.add_argument("--no-labels", action="store_true", help="streamed mode: label map not materialised (config #5)")
+    ap.add_argument("--cpu-frames", type=int, default=13, help="frames of the CPU-baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from imageprocessing_amd import sharding, synth
+    from imageprocessing_amd.engine import Segmenter
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
+
+    seg = Segmenter(H, W, max_frames=BATCH, device=local_rank)
+    mask = seg.disk_mask(1200)
+    cfg = synth.CONFIGS[args.workload]
+    nb = max(1, min(args.batches, args.steps + args.warmup))
+    seed = 2 + 1000 * rank
+    stacks = []
+    for b in range(nb):
+        objs, off = synth.make_objects(BATCH, H, W, seed, frame0=b * BATCH, **cfg)
+        stacks.append(seg.synth_frames(BATCH, seed, objs, off, frame0=b * BATCH))
+    cleaned = torch.empty((BATCH, H, W), dtype=torch.uint8, device=dev)
+    labels = None if args.no_labels else torch.empty((BATCH, H, W), dtype=torch.int32, device=dev)
+
+    group_ms = {k: 0.0 for k in GROUP_NAMES}
+    stats = dict(rows=0, saved=0, crop_bytes=0, contours=0)
+
+    def step(i, timed):
+        _, _, _, tab = seg.process(stacks[i % nb], mask=mask, cleaned=cleaned, labels=labels)
+        if world > 1:
+            sharding.gather_tables(sharding.pack_table(tab, frame_base=(rank * nb + i % nb) * BATCH), device=dev)
+        if timed:
+            for k in GROUP_NAMES:
+                group_ms[k] += seg.last_ms(k)
+            stats["rows"] += tab.n_rows
+            stats["saved"] += int(tab.saved.sum())
+            stats["crop_bytes"] += tab.crop_bytes
+            stats["contours"] += int(tab.frame_n_contours.sum())
+
+    for i in range(args.warmup):
+        step(i, False)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i, True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    frames = args.steps * BATCH * world
+    fps = frames / elapsed
+    # dominant kernel group by device time (HIP events inside the library, on its own stream)
+    dom = max(GROUP_NAMES, key=lambda k: group_ms[k])
+    dom_name = GROUP_NAMES[dom]
+    dom_ms = group_ms[dom] / args.steps
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(dom_name)
+        except Exception:
+            traffic = None
+    if dom_name in GROUP_BYTES:
+        launch_bytes = GROUP_BYTES[dom_name] * BATCH
+    else:   # sparse groups: their share of the path's compulsory bytes is the object payload only
+        launch_bytes = (stats["crop_bytes"] * 3 + stats["rows"] * 44 * 8) / max(args.steps, 1)
+    achieved = launch_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    out = {
+        "metric": "frames/sec (2560x2560 uint8), hot path bg_correction+detection",
+        "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": f"configs[1]: {nb * BATCH}-frame {args.workload} stack per GPU, batches of {BATCH}, bg window 12, "
+                               f"~{cfg['per_frame']} objects/frame, label map {'off' if args.no_labels else 'on'}",
+                   "frames_per_step": BATCH, "objects_per_frame": round(stats["contours"] / (args.steps * BATCH), 1),
+                   "rows_per_frame": round(stats["rows"] / (args.steps * BATCH), 1),
+                   "saved_per_frame": round(stats["saved"] / (args.steps * BATCH), 1)},
+        "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "avg_launch_ms": round(dom_ms, 4), "bytes_per_launch": int(launch_bytes)},
+        "path": {"bytes_per_frame": PATH_BYTES_PER_FRAME if not args.no_labels else 2 * P,
+                 "frac_of_hbm_peak_per_gpu": round(fps / world * (PATH_BYTES_PER_FRAME if not args.no_labels else 2 * P) / (HBM_PEAK_GBS * 1e9), 4),
+                 "group_ms_per_step": {GROUP_NAMES[k]: round(group_ms[k] / args.steps, 3) for k in GROUP_NAMES}},
+    }
+
+    if rank == 0 and world == 1 and args.cpu_frames >= 12:
+        from tests import helpers          # the oracle is the timed CPU port here, never the product path
+        nf = args.cpu_frames
+        sample = stacks[0][:nf].cpu().numpy()
+        hmask = mask.cpu().numpy()
+        c0 = time.perf_counter()
+        items = helpers.oracle_bgcorrect(sample)
+        helpers.oracle_detect(items, hmask, want_labels=False)
+        ct = time.perf_counter() - c0
+        out["cpu_baseline"] = {"value": round(nf / ct, 3), "unit": "frames/s", "cores": 1, "kind": "port",
+                               "sample": f"first {nf} frames of batch 0 treated as one batch (window 12), NumPy + C oracle, "
+                                         f"single thread, no PNG/CSV writes, host has {os.cpu_count()} logical CPUs"}
+    if rank == 0:
+        print(json.dumps(out))
+    seg.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -53,6 +53,10 @@ struct pseg_ctx {
         keptrank, savedrank, objlabel, objflag;
     DevBuf rows, saved_row, saved_geo, crop_off, bits_off, maskbits, sums, crops_raw, crops_masked, crops_mask, totals;
     bool have_bits = false;       // threshold plane + masked sums already produced by the bg kernel
+    DevBuf bounds;
+    int bounds_n = -1, bounds_chunks = -1;
+    int bg_chunks = 1;            // time chunks of the streaming background kernel (PSEG_BG_CHUNKS)
+    bool force_generic = false;   // PSEG_BG_GENERIC=1: use the 12x-read reference kernel (debug / cross-check)
     // host results
     HostBuf h_frame_row_offset, h_frame_n_contours, h_frame_valid, h_frame_mean, h_frame_std, h_rows, h_area,
         h_saved8, h_props, h_saved_row, h_crop_off, h_sums, h_tmp;
@@ -179,6 +183,167 @@ __global__ __launch_bounds__(256) void k_bg_generic(const uint8_t *__restrict__ 
         bits8[(size_t)f * (P / 8) + strip] = (uint8_t)b;
     }
     block_sum4_store(s0, s1, s2, s3, partials + ((size_t)f * gridDim.x + blockIdx.x) * 4);
+}
+
+// ------------------------------------------------------------------------------------------------
+// streaming background kernel (window of 12 frames = the reference's 2*n_bg_imgs with n_bg_imgs = 6)
+//
+// A thread owns one 8-pixel strip and walks the frames of its time chunk [a, b) in order, so every
+// raw byte is read from HBM once (plus an 11-frame halo per chunk) instead of 12 times.
+//   m[j]   = min(I[j], I[j+1])                          (pair minima, bg_correction.py:76)
+//   bg[s]  = max(m[s] .. m[s+10])                       (bg_correction.py:78) as a trailing sparse table:
+//            T2[j] = max(m[j], m[j-1]); T4[j] = max(T2[j], T2[j-2]); T8[j] = max(T4[j], T4[j-4]);
+//            T11[j] = max(T8[j], T8[j-3]) = max(m[j-10..j]) = bg[j-10]
+//   frame s = j-10 is emitted when frame j+1 arrives; the last 12 frames share bg[n-12] (:72) and are
+//   emitted together when frame n-1 arrives.
+// Pixel values live as u16 pairs (even / odd bytes of a dword) so that v_pk_min/max/sub_u16 apply.
+// All rings are indexed with compile-time phases (loop unrolled by 16); 4 loads stay in flight.
+// No LDS, no barriers: each wave reduces its four sums with DPP and lane 63 stores them.
+// ------------------------------------------------------------------------------------------------
+typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pkmax(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2_t, a), __builtin_bit_cast(u16x2_t, b))); }
+__device__ __forceinline__ uint32_t pkmin(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2_t, a), __builtin_bit_cast(u16x2_t, b))); }
+__device__ __forceinline__ uint32_t pksub(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, (u16x2_t)(__builtin_bit_cast(u16x2_t, a) - __builtin_bit_cast(u16x2_t, b))); }
+template <int CTRL, int RM> __device__ __forceinline__ uint32_t dpp_add(uint32_t v) { return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, RM, 0xf, false); }
+// sum over the wave, valid in lane 63
+__device__ __forceinline__ uint32_t wave_sum63(uint32_t v)
+{
+    v = dpp_add<0x111, 0xf>(v); v = dpp_add<0x112, 0xf>(v); v = dpp_add<0x114, 0xf>(v); v = dpp_add<0x118, 0xf>(v);
+    v = dpp_add<0x142, 0xa>(v);     // row_bcast:15 into rows 1,3
+    v = dpp_add<0x143, 0xc>(v);     // row_bcast:31 into rows 2,3
+    return v;
+}
+struct Px8 { uint32_t e0, o0, e1, o1; };      // 8 pixels as four registers of two u16 lanes
+__device__ __forceinline__ Px8 px_split(uint2 v)
+{
+    Px8 r;
+    r.e0 = __builtin_amdgcn_perm(0, v.x, 0x0c020c00); r.o0 = __builtin_amdgcn_perm(0, v.x, 0x0c030c01);
+    r.e1 = __builtin_amdgcn_perm(0, v.y, 0x0c020c00); r.o1 = __builtin_amdgcn_perm(0, v.y, 0x0c030c01);
+    return r;
+}
+__device__ __forceinline__ Px8 px_max(Px8 a, Px8 b) { return {pkmax(a.e0, b.e0), pkmax(a.o0, b.o0), pkmax(a.e1, b.e1), pkmax(a.o1, b.o1)}; }
+__device__ __forceinline__ Px8 px_min(Px8 a, Px8 b) { return {pkmin(a.e0, b.e0), pkmin(a.o0, b.o0), pkmin(a.e1, b.e1), pkmin(a.o1, b.o1)}; }
+
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint2 ld_stream(const uint8_t *p)
+{
+    u32x2_t v = __builtin_nontemporal_load((const u32x2_t *)p);
+    return make_uint2(v.x, v.y);
+}
+struct BgEmit {
+    uint8_t *cleaned; uint8_t *bits8; uint4 *partials; size_t P, strip; uint2 inm; uint32_t kthr; int thr_hi; uint32_t nwaves, wave;
+    uint32_t act;          // 0xffffffff for strips inside the frame, 0 for the padding lanes of the last wave
+};
+// bit 7 of every byte of x that is >= t (1 <= t <= 255), kt = t (t <= 128) or t-128, replicated
+__device__ __forceinline__ uint32_t bytes_ge(uint32_t x, uint32_t kt, int hi)
+{
+    uint32_t y = ((x & 0x7f7f7f7fu) | 0x80808080u) - kt;
+    return (hi ? (y & x) : (y | x)) & 0x80808080u;
+}
+__device__ __forceinline__ uint32_t gather4(uint32_t r)     // bits 7,15,23,31 -> bits 0..3
+{
+    r >>= 7; r |= r >> 7; r |= r >> 14;
+    return r & 0xfu;
+}
+__device__ __forceinline__ void bg_emit(const BgEmit &E, uint2 img, Px8 bg, int s)
+{
+    Px8 c = px_split(img);
+    uint32_t de0 = pksub(pkmax(c.e0, bg.e0), pkmin(c.e0, bg.e0)), do0 = pksub(pkmax(c.o0, bg.o0), pkmin(c.o0, bg.o0));
+    uint32_t de1 = pksub(pkmax(c.e1, bg.e1), pkmin(c.e1, bg.e1)), do1 = pksub(pkmax(c.o1, bg.o1), pkmin(c.o1, bg.o1));
+    uint2 corr = make_uint2(__builtin_amdgcn_perm(do0, de0, 0x06020400), __builtin_amdgcn_perm(do1, de1, 0x06020400));   // :80
+    if (E.act) *(uint2 *)(E.cleaned + (size_t)s * E.P + E.strip * 8) = make_uint2(~corr.x, ~corr.y);                 // :81
+    uint2 cm = make_uint2(corr.x & E.inm.x, corr.y & E.inm.y);
+    img.x &= E.act; img.y &= E.act;
+    uint32_t s0 = __builtin_amdgcn_sad_u8(img.x, 0u, __builtin_amdgcn_sad_u8(img.y, 0u, 0u));
+    uint32_t s1 = __builtin_amdgcn_udot4(img.x, img.x, __builtin_amdgcn_udot4(img.y, img.y, 0u, false), false);
+    uint32_t s2 = __builtin_amdgcn_sad_u8(cm.x, 0u, __builtin_amdgcn_sad_u8(cm.y, 0u, 0u));
+    uint32_t s3 = __builtin_amdgcn_udot4(cm.x, cm.x, __builtin_amdgcn_udot4(cm.y, cm.y, 0u, false), false);
+    uint32_t b = 0;
+    if (E.kthr) b = gather4(bytes_ge(cm.x, E.kthr, E.thr_hi)) | (gather4(bytes_ge(cm.y, E.kthr, E.thr_hi)) << 4);
+    if (E.act) E.bits8[(size_t)s * (E.P / 8) + E.strip] = (uint8_t)b;
+    s0 = wave_sum63(s0); s1 = wave_sum63(s1); s2 = wave_sum63(s2); s3 = wave_sum63(s3);
+    if ((threadIdx.x & 63) == 63) E.partials[(size_t)s * E.nwaves + E.wave] = make_uint4(s0, s1, s2, s3);
+}
+
+struct BgRing {
+    uint2 raw[16];
+    Px8 ps, mp, t2[2], t4[4], t8[4];
+};
+template <int PH>
+__device__ __forceinline__ void bg_step(BgRing &R, const BgEmit &E, const uint8_t *__restrict__ src, int k, int a, int kend, int n)
+{
+    if (k < a || k > kend) return;
+    if (k + 4 <= kend) R.raw[(PH + 4) & 15] = ld_stream(src + (size_t)(k + 4) * E.P);
+    Px8 ce = px_split(R.raw[PH]);
+    if (k > a) {
+        Px8 m = px_min(R.ps, ce);
+        Px8 t2 = px_max(m, R.mp); R.mp = m;
+        Px8 t4 = px_max(t2, R.t2[(PH + 1) & 1]); R.t2[(PH + 1) & 1] = t2;
+        Px8 t8 = px_max(t4, R.t4[(PH + 3) & 3]); R.t4[(PH + 3) & 3] = t4;
+        Px8 t11 = px_max(t8, R.t8[PH & 3]); R.t8[(PH + 3) & 3] = t8;
+        if (k < n - 1) {
+            if (k - 11 >= a) bg_emit(E, R.raw[(PH + 5) & 15], t11, k - 11);
+        } else if (PH == 15) {                              // k == n-1: the last 12 frames share this background
+#pragma unroll
+            for (int i = 0; i < 12; i++) bg_emit(E, R.raw[(PH + 5 + i) & 15], t11, n - 12 + i);
+        }
+    }
+    R.ps = ce;
+}
+
+// grid = (ceil(P/2048), chunks); chunk c emits frames [bounds[c], bounds[c+1])
+__global__ __launch_bounds__(256) void k_bg_stream(const uint8_t *__restrict__ frames, int n, size_t P, uint8_t *__restrict__ cleaned,
+                                                   const uint8_t *__restrict__ mask, int thr, uint8_t *__restrict__ bits8,
+                                                   uint4 *__restrict__ partials, const int *__restrict__ bounds)
+{
+    size_t strip = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const bool act = strip * 8 < P;                         // padding lanes stay in the wave (DPP sums), load strip 0, store nothing
+    if (!act) strip = 0;
+    const int a = bounds[blockIdx.y], b = bounds[blockIdx.y + 1];
+    const int kend = (b == n) ? n - 1 : b + 10;
+    BgEmit E;
+    E.cleaned = cleaned; E.bits8 = bits8; E.partials = partials; E.P = P; E.strip = strip;
+    E.inm = make_uint2(0xffffffffu, 0xffffffffu);
+    if (mask) { uint2 m = *(const uint2 *)(mask + strip * 8); E.inm = make_uint2(eq255_4(m.x), eq255_4(m.y)); }
+    E.act = act ? 0xffffffffu : 0u;
+    E.inm.x &= E.act; E.inm.y &= E.act;
+    int t1 = thr + 1;                                       // pixel > thr  <=>  pixel >= thr + 1
+    E.kthr = (t1 >= 1 && t1 <= 255) ? (uint32_t)(t1 <= 128 ? t1 : t1 - 128) * 0x01010101u : 0u;
+    E.thr_hi = t1 > 128;
+    E.nwaves = gridDim.x * 4; E.wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint8_t *src = frames + strip * 8;
+    BgRing R;
+    const Px8 z = {0, 0, 0, 0};
+    R.ps = z; R.mp = z;
+    for (int i = 0; i < 2; i++) R.t2[i] = z;
+    for (int i = 0; i < 4; i++) { R.t4[i] = z; R.t8[i] = z; }
+    // phase of frame k is (k - kbase) & 15 with the chunk's last frame on phase 15
+    const int kbase = kend - 15 - 16 * ((kend - a) / 16);
+    {   // prologue: the first four frames of the chunk (their ring slots follow from the phase rule)
+        uint2 f0 = ld_stream(src + (size_t)a * P);
+        uint2 f1 = a + 1 <= kend ? ld_stream(src + (size_t)(a + 1) * P) : f0;
+        uint2 f2 = a + 2 <= kend ? ld_stream(src + (size_t)(a + 2) * P) : f0;
+        uint2 f3 = a + 3 <= kend ? ld_stream(src + (size_t)(a + 3) * P) : f0;
+        const int p0 = (a - kbase) & 15;
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            if (q == p0) R.raw[q] = f0;
+            else if (q == ((p0 + 1) & 15)) R.raw[q] = f1;
+            else if (q == ((p0 + 2) & 15)) R.raw[q] = f2;
+            else if (q == ((p0 + 3) & 15)) R.raw[q] = f3;
+            else R.raw[q] = make_uint2(0, 0);
+        }
+    }
+    for (int kb = kbase; kb <= kend; kb += 16) {
+        bg_step<0>(R, E, src, kb + 0, a, kend, n);   bg_step<1>(R, E, src, kb + 1, a, kend, n);
+        bg_step<2>(R, E, src, kb + 2, a, kend, n);   bg_step<3>(R, E, src, kb + 3, a, kend, n);
+        bg_step<4>(R, E, src, kb + 4, a, kend, n);   bg_step<5>(R, E, src, kb + 5, a, kend, n);
+        bg_step<6>(R, E, src, kb + 6, a, kend, n);   bg_step<7>(R, E, src, kb + 7, a, kend, n);
+        bg_step<8>(R, E, src, kb + 8, a, kend, n);   bg_step<9>(R, E, src, kb + 9, a, kend, n);
+        bg_step<10>(R, E, src, kb + 10, a, kend, n); bg_step<11>(R, E, src, kb + 11, a, kend, n);
+        bg_step<12>(R, E, src, kb + 12, a, kend, n); bg_step<13>(R, E, src, kb + 13, a, kend, n);
+        bg_step<14>(R, E, src, kb + 14, a, kend, n); bg_step<15>(R, E, src, kb + 15, a, kend, n);
+    }
 }
 
 // detection.py:178-202 for a cleaned image that did not come from k_bg_* (e.g. after deconvolution)
@@ -521,6 +686,8 @@ extern "C" int pseg_create(int device, int H, int W, int max_frames, pseg_ctx **
     ctx->device = device; ctx->H = H; ctx->W = W; ctx->WW = W / 64; ctx->maxF = max_frames; ctx->P = (size_t)H * W;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&ctx->stream) != hipSuccess) { delete ctx; return PSEG_ERR_HIP; }
     ctx->own_stream = true;
+    if (const char *e = getenv("PSEG_BG_CHUNKS")) ctx->bg_chunks = atoi(e) > 0 ? atoi(e) : 1;
+    if (const char *e = getenv("PSEG_BG_GENERIC")) ctx->force_generic = atoi(e) != 0;
     for (auto &e : ctx->ev) if (hipEventCreate(&e) != hipSuccess) { delete ctx; return PSEG_ERR_HIP; }
     *out = ctx;
     return PSEG_OK;
@@ -536,7 +703,7 @@ extern "C" int pseg_destroy(pseg_ctx *ctx)
                       &ctx->bg_parent, &ctx->bg_left, &ctx->minx, &ctx->maxx, &ctx->miny, &ctx->maxy, &ctx->area2,
                       &ctx->extrank, &ctx->keptrank, &ctx->savedrank, &ctx->objlabel, &ctx->objflag, &ctx->rows,
                       &ctx->saved_row, &ctx->saved_geo, &ctx->crop_off, &ctx->bits_off, &ctx->maskbits, &ctx->sums,
-                      &ctx->crops_raw, &ctx->crops_masked, &ctx->crops_mask, &ctx->totals};
+                      &ctx->crops_raw, &ctx->crops_masked, &ctx->crops_mask, &ctx->totals, &ctx->bounds};
     for (DevBuf *b : bufs) if (b->p) hipFree(b->p);
     for (auto &e : ctx->ev) if (e) hipEventDestroy(e);
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
@@ -572,16 +739,37 @@ static int run_bg(pseg_ctx *ctx, const uint8_t *frames, int n, int n_bg_imgs, co
     if (n_bg_imgs < 1 || 2 * n < NW) return fail(ctx, PSEG_ERR_ARG, "need n >= n_bg_imgs (reference raises IndexError below that)");
     size_t P = ctx->P;
     unsigned nblk = nblocks(P / 8);
+    const bool stream = (NW == 12 && n >= 12 && !ctx->force_generic);
+    unsigned npart = stream ? nblk * 4 : nblk;               // partial sums per frame: per wave / per block
     ENSURE(ctx->bits, (size_t)n * P / 8);
-    ENSURE(ctx->partials, (size_t)n * nblk * 4 * sizeof(uint32_t));
+    ENSURE(ctx->partials, (size_t)n * npart * 4 * sizeof(uint32_t));
     ENSURE(ctx->fsums, (size_t)n * 4 * sizeof(uint64_t));
     ENSURE(ctx->valid_dev, (size_t)n);
+    int chunks = 1;
+    if (stream) {
+        chunks = ctx->bg_chunks;
+        if (chunks > n - 12) chunks = n - 12;
+        if (chunks < 1) chunks = 1;
+        if (ctx->bounds_n != n || ctx->bounds_chunks != chunks) {
+            std::vector<int> bnd(chunks + 1);
+            for (int c = 0; c < chunks; c++) bnd[c] = (int)((long long)c * (n - 12) / chunks);
+            bnd[chunks] = n;
+            ENSURE(ctx->bounds, (size_t)(chunks + 1) * 4);
+            HIPCHK(hipMemcpyAsync(ctx->bounds.p, bnd.data(), (size_t)(chunks + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            ctx->bounds_n = n; ctx->bounds_chunks = chunks;
+        }
+    }
     HIPCHK(hipEventRecord(ctx->ev[0], ctx->stream));
-    hipLaunchKernelGGL(k_bg_generic, dim3(nblk, n), dim3(256), 0, ctx->stream, frames, n, NW, P, cleaned, mask, thr,
-                       (uint8_t *)ctx->bits.p, (uint32_t *)ctx->partials.p);
+    if (stream)
+        hipLaunchKernelGGL(k_bg_stream, dim3(nblk, chunks), dim3(256), 0, ctx->stream, frames, n, P, cleaned, mask, thr,
+                           (uint8_t *)ctx->bits.p, (uint4 *)ctx->partials.p, (const int *)ctx->bounds.p);
+    else
+        hipLaunchKernelGGL(k_bg_generic, dim3(nblk, n), dim3(256), 0, ctx->stream, frames, n, NW, P, cleaned, mask, thr,
+                           (uint8_t *)ctx->bits.p, (uint32_t *)ctx->partials.p);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
-    hipLaunchKernelGGL(k_reduce_partials, dim3(n), dim3(256), 0, ctx->stream, (const uint32_t *)ctx->partials.p, (int)nblk,
+    hipLaunchKernelGGL(k_reduce_partials, dim3(n), dim3(256), 0, ctx->stream, (const uint32_t *)ctx->partials.p, (int)npart,
                        (unsigned long long)P, (unsigned long long *)ctx->fsums.p, (uint8_t *)ctx->valid_dev.p, 1, 0, 4);
     HIPCHK(hipGetLastError());
     return 0;

@@ -56,12 +56,16 @@ def convex_hull_mask(M):
     +-0.5 diamond points of the row/column-extremal pixels, then every pixel centre inside or on
     the hull polygon.  Done here in exact integer arithmetic on doubled coordinates."""
     H, W = M.shape
-    rr, cc = np.nonzero(M)
-    if rr.size == 0:
+    if not M.any():
         return np.zeros_like(M, bool)
     pts = set()
-    for r, c in zip(rr.tolist(), cc.tolist()):
-        pts.update(((2 * r - 1, 2 * c), (2 * r + 1, 2 * c), (2 * r, 2 * c - 1), (2 * r, 2 * c + 1)))
+    rows = np.nonzero(M.any(axis=1))[0]
+    first = M.argmax(axis=1)
+    last = W - 1 - M[:, ::-1].argmax(axis=1)
+    # row-extremal pixels carry the hull (possible_hull also adds column extremes: same hull)
+    for r in rows.tolist():
+        for c in (int(first[r]), int(last[r])):
+            pts.update(((2 * r - 1, 2 * c), (2 * r + 1, 2 * c), (2 * r, 2 * c - 1), (2 * r, 2 * c + 1)))
     P = sorted(pts)
     lower, upper = [], []
     for p in P:

@@ -94,3 +94,30 @@ def test_disk_mask(gpu_seg_factory):
     for H, W, r in [(256, 256, 120), (128, 128, 70), (64, 64, 10)]:
         seg = gpu_seg_factory(H, W)
         assert np.array_equal(seg.disk_mask(r).cpu().numpy(), helpers.make_disk(H, W, r))
+
+
+@pytest.mark.parametrize("n,chunks", [(12, 1), (13, 1), (27, 2), (28, 1), (29, 3), (45, 1), (61, 5), (200, 4)])
+def test_bg_stream_kernel_vs_oracle(monkeypatch, n, chunks):
+    """Streaming background kernel (one HBM read per raw byte) for every ring phase / chunking."""
+    import torch
+    from imageprocessing_amd.engine import Segmenter
+    monkeypatch.setenv("PSEG_BG_CHUNKS", str(chunks))
+    H, W = 64, 128
+    seg = Segmenter(H, W, max_frames=n, device=0)
+    rng = np.random.default_rng(100 + n)
+    stack = rng.integers(0, 256, (n, H, W), dtype=np.uint8)
+    stack[n // 3] = 9
+    mask = helpers.make_disk(H, W, 30)
+    items = helpers.oracle_bgcorrect(stack)
+    cleaned, ms, valid, tab = seg.process(torch.from_numpy(stack).cuda(), mask=torch.from_numpy(mask).cuda(), threshold=100)
+    cleaned = cleaned.cpu().numpy()
+    for i, it in enumerate(items):
+        np.testing.assert_allclose(ms[i], it[2], rtol=1e-9, atol=1e-9)
+        assert valid[i] == (0 if isinstance(it[1], list) else 1)
+        if valid[i]:
+            assert np.array_equal(cleaned[i], it[1]), f"frame {i}"
+            corr = (255 - it[1])[mask == 255]
+            np.testing.assert_allclose([tab.frame_mean[i], tab.frame_std[i]], [corr.mean(), corr.std()], rtol=1e-9)
+            thr = ((255 - it[1]) > 100) & (mask == 255)
+            assert tab.frame_n_contours[i] == len(helpers.cv_ref.findContours(thr.astype(np.uint8), 0, 2)[0])
+    seg.close()
