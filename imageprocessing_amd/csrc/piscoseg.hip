@@ -53,7 +53,7 @@ struct pseg_ctx {
         keptrank, savedrank, objlabel, objflag;
     DevBuf rows, saved_row, saved_geo, crop_off, bits_off, maskbits, sums, crops_raw, crops_masked, crops_mask, totals;
     bool have_bits = false;       // threshold plane + masked sums already produced by the bg kernel
-    DevBuf bounds;
+    DevBuf bounds, band_off;
     int bounds_n = -1, bounds_chunks = -1;
     int bg_chunks = 1;            // time chunks of the streaming background kernel (PSEG_BG_CHUNKS)
     bool force_generic = false;   // PSEG_BG_GENERIC=1: use the 12x-read reference kernel (debug / cross-check)
@@ -267,7 +267,7 @@ __device__ __forceinline__ void bg_emit(const BgEmit &E, uint2 img, Px8 bg, int 
 
 struct BgRing {
     uint2 raw[16];
-    Px8 ps, mp, t2[2], t4[4], t8[4];
+    Px8 mp, t2[2], t4[4], t8[4];
 };
 template <int PH>
 __device__ __forceinline__ void bg_step(BgRing &R, const BgEmit &E, const uint8_t *__restrict__ src, int k, int a, int kend, int n)
@@ -276,23 +276,22 @@ __device__ __forceinline__ void bg_step(BgRing &R, const BgEmit &E, const uint8_
     if (k + 4 <= kend) R.raw[(PH + 4) & 15] = ld_stream(src + (size_t)(k + 4) * E.P);
     Px8 ce = px_split(R.raw[PH]);
     if (k > a) {
-        Px8 m = px_min(R.ps, ce);
+        Px8 m = px_min(px_split(R.raw[(PH + 15) & 15]), ce);   // previous frame re-split: 4 ops instead of 4 live registers
         Px8 t2 = px_max(m, R.mp); R.mp = m;
         Px8 t4 = px_max(t2, R.t2[(PH + 1) & 1]); R.t2[(PH + 1) & 1] = t2;
         Px8 t8 = px_max(t4, R.t4[(PH + 3) & 3]); R.t4[(PH + 3) & 3] = t4;
         Px8 t11 = px_max(t8, R.t8[PH & 3]); R.t8[(PH + 3) & 3] = t8;
         if (k < n - 1) {
             if (k - 11 >= a) bg_emit(E, R.raw[(PH + 5) & 15], t11, k - 11);
-        } else if (PH == 15) {                              // k == n-1: the last 12 frames share this background
-#pragma unroll
-            for (int i = 0; i < 12; i++) bg_emit(E, R.raw[(PH + 5 + i) & 15], t11, n - 12 + i);
+        } else {                                            // k == n-1: the last 12 frames share this background;
+#pragma unroll 1                                            // they are re-read (cache hits) to keep the ring indices static
+            for (int i = n - 12; i < n; i++) bg_emit(E, ld_stream(src + (size_t)i * E.P), t11, i);
         }
     }
-    R.ps = ce;
 }
 
 // grid = (ceil(P/2048), chunks); chunk c emits frames [bounds[c], bounds[c+1])
-__global__ __launch_bounds__(256) void k_bg_stream(const uint8_t *__restrict__ frames, int n, size_t P, uint8_t *__restrict__ cleaned,
+__global__ __launch_bounds__(256, 4) void k_bg_stream(const uint8_t *__restrict__ frames, int n, size_t P, uint8_t *__restrict__ cleaned,
                                                    const uint8_t *__restrict__ mask, int thr, uint8_t *__restrict__ bits8,
                                                    uint4 *__restrict__ partials, const int *__restrict__ bounds)
 {
@@ -314,7 +313,7 @@ __global__ __launch_bounds__(256) void k_bg_stream(const uint8_t *__restrict__ f
     const uint8_t *src = frames + strip * 8;
     BgRing R;
     const Px8 z = {0, 0, 0, 0};
-    R.ps = z; R.mp = z;
+    R.mp = z;
     for (int i = 0; i < 2; i++) R.t2[i] = z;
     for (int i = 0; i < 4; i++) { R.t4[i] = z; R.t8[i] = z; }
     // phase of frame k is (k - kbase) & 15 with the chunk's last frame on phase 15
@@ -392,11 +391,13 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const uint32_t *__restr
     }
 }
 
-__global__ void k_mask_count(const uint8_t *__restrict__ mask, size_t P, unsigned long long *cnt)
+__global__ __launch_bounds__(256) void k_mask_count(const uint8_t *__restrict__ mask, size_t P, unsigned long long *cnt)
 {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t c = 0;
-    if (i * 8 < P) { uint2 m = *(const uint2 *)(mask + i * 8); c = __popc(eq255_4(m.x) & 0x01010101u) + __popc(eq255_4(m.y) & 0x01010101u); }
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i * 8 < P; i += (size_t)gridDim.x * blockDim.x) {
+        uint2 m = *(const uint2 *)(mask + i * 8);
+        c += __popc(eq255_4(m.x) & 0x01010101u) + __popc(eq255_4(m.y) & 0x01010101u);
+    }
     c = wave_sum_u32(c);
     if ((threadIdx.x & 63) == 0 && c) atomicAdd(cnt, (unsigned long long)c);
 }
@@ -550,39 +551,84 @@ __global__ void k_emit(SegState S, int nfg, double min_seg, double min_save, con
     if (saved) saved_row[(int)savedbase[f] + (nsaved - 1 - S.savedrank[r])] = i;
 }
 
-// label map: zero fill is done by a memset; thread per run writes its label
-__global__ void k_label_runs(SegState S, int nfg, const int32_t *objlabel, int32_t *labels)
+// label map: one dense pass writes every int32 exactly once.  Thread = 4 pixels
+// (one 16-byte store, 1 KiB per wave); the 4 threshold bits decide between a zero store and a run
+// lookup (binary search in the row's runs).  grid = (P/1024, frames).
+typedef int32_t i32x4_t __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_label_fill(SegState S, const int32_t *__restrict__ objlabel, int32_t *__restrict__ labels)
 {
-    size_t g = GTID;
-    if (g >= (size_t)nfg) return;
-    int r = (int)g;
-    int E = S.ext[r];
-    if (S.fg_parent[r] != E) return;                        // component nested in a hole: label 0
-    int lab = objlabel[E];
-    int y = (int)(S.run_fy[r] & 0xffffu), f = (int)(S.run_fy[r] >> 16);
-    int32_t *row = labels + ((size_t)f * S.H + y) * S.W;
-    for (int x = run_xs(S, r); x <= run_xe(S, r); x++) row[x] = lab;
+    const size_t P = (size_t)S.H * S.W;
+    size_t pix = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (pix >= P) return;
+    int f = blockIdx.y;
+    uint32_t nib = (((const uint8_t *)S.bits)[((size_t)f * P + pix) >> 3] >> (pix & 4)) & 0xfu;
+    i32x4_t out = {0, 0, 0, 0};
+    if (nib && S.valid[f]) {
+        int y = (int)(pix / S.W), x = (int)(pix - (size_t)y * S.W);
+        int rs = seg_rowstart(S, f, y), n = seg_rowcount(S, f, y);
+        int lo = 0, hi = n;                                  // first run with xe >= x
+        while (lo < hi) { int m = (lo + hi) >> 1; if (run_xe(S, rs + m) >= x) hi = m; else lo = m + 1; }
+        for (int q = rs + lo; q < rs + n; q++) {
+            int xs = run_xs(S, q), xe = run_xe(S, q);
+            if (xs > x + 3) break;
+            int E = S.ext[q];
+            int lab = (S.fg_parent[q] == E) ? objlabel[E] : 0;   // components nested in holes keep 0
+            if (xs <= x && x <= xe) out.x = lab;
+            if (xs <= x + 1 && x + 1 <= xe) out.y = lab;
+            if (xs <= x + 2 && x + 2 <= xe) out.z = lab;
+            if (xs <= x + 3 && x + 3 <= xe) out.w = lab;
+        }
+    }
+    __builtin_nontemporal_store(out, (i32x4_t *)(labels + (size_t)f * P + pix));
 }
 
-// geometry of saved object s: saved_geo[s*8] = f, x, y, w, h, root, words-per-row, 0 ; sizes for the scans
-__global__ void k_saved_geo(int n_saved, const int32_t *saved_row, RowsDev R, int32_t *geo, unsigned long long *sz)
+// geometry of saved object s: geo[s*8] = f, x, y, w, h, root, words-per-row, row ; sz[s*3] = crop bytes,
+// mask words, row bands (a band = a run of rows of about CROP_BAND pixels: the unit of work of k_crops_sums)
+#define CROP_BAND 4096
+__host__ __device__ inline int crop_rows_per_band(int w) { int r = CROP_BAND / w; return r < 1 ? 1 : r; }
+__global__ void k_saved_geo(const uint32_t *n_saved_p, const int32_t *saved_row, RowsDev R, int32_t *geo, unsigned long long *sz)
 {
     size_t g = GTID;
-    if (g >= (size_t)n_saved) return;
+    if (g >= (size_t)*n_saved_p) return;
     int i = saved_row[g];
     int w = R.w[i], h = R.h[i], wpr = (w + 31) >> 5;
     int32_t *o = geo + 8 * g;
     o[0] = R.frame[i]; o[1] = R.x[i]; o[2] = R.y[i]; o[3] = w; o[4] = h; o[5] = R.root[i]; o[6] = wpr; o[7] = i;
-    sz[2 * g] = (unsigned long long)w * h;
-    sz[2 * g + 1] = (unsigned long long)wpr * h;
+    int rpb = crop_rows_per_band(w);
+    sz[3 * g] = (unsigned long long)w * h;
+    sz[3 * g + 1] = (unsigned long long)wpr * h;
+    sz[3 * g + 2] = (unsigned long long)((h + rpb - 1) / rpb);
 }
-__global__ void k_scan_sizes(const unsigned long long *sz, int n, long long *crop_off, long long *bits_off)
+// exclusive scans of the three size columns by one block of 1024 threads; out[k][0..n]
+__global__ __launch_bounds__(1024) void k_scan_sizes(const unsigned long long *sz, const uint32_t *n_p, long long *crop_off,
+                                                      long long *bits_off, long long *band_off, long long *totals)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        long long a = 0, b = 0;
-        for (int s = 0; s < n; s++) { crop_off[s] = a; bits_off[s] = b; a += (long long)sz[2 * s]; b += (long long)sz[2 * s + 1]; }
-        crop_off[n] = a; bits_off[n] = b;
+    __shared__ unsigned long long sh[3][1024];
+    __shared__ unsigned long long carry[3];
+    const int n = (int)*n_p;
+    if (threadIdx.x < 3) carry[threadIdx.x] = 0;
+    __syncthreads();
+    long long *outp[3] = {crop_off, bits_off, band_off};
+    for (int base = 0; base < n; base += 1024) {
+        int i = base + threadIdx.x;
+        unsigned long long v[3] = {0, 0, 0};
+        if (i < n) for (int k = 0; k < 3; k++) v[k] = sz[3 * (size_t)i + k];
+        for (int k = 0; k < 3; k++) sh[k][threadIdx.x] = v[k];
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            unsigned long long t[3];
+            for (int k = 0; k < 3; k++) t[k] = threadIdx.x >= o ? sh[k][threadIdx.x - o] : 0;
+            __syncthreads();
+            for (int k = 0; k < 3; k++) sh[k][threadIdx.x] += t[k];
+            __syncthreads();
+        }
+        unsigned long long c0[3] = {carry[0], carry[1], carry[2]};
+        if (i < n) for (int k = 0; k < 3; k++) outp[k][i] = (long long)(c0[k] + sh[k][threadIdx.x] - v[k]);
+        __syncthreads();
+        if (threadIdx.x == 1023) for (int k = 0; k < 3; k++) carry[k] = c0[k] + sh[k][1023];
+        __syncthreads();
     }
+    if (threadIdx.x < 3) { outp[threadIdx.x][n] = (long long)carry[threadIdx.x]; totals[threadIdx.x] = (long long)carry[threadIdx.x]; }
 }
 
 // cumulative filled mask window of saved object s as bits (block per object, thread per 32-px word).
@@ -605,43 +651,50 @@ __global__ __launch_bounds__(256) void k_build_masks(SegState S, const int32_t *
     }
 }
 
-__device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v, unsigned long long *sh)
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return sh[0] + sh[1] + sh[2] + sh[3];
+    return v;
 }
 
-// three crops + integer sums of saved object s (block per object).
+// three crops + integer sums of one row band of a saved object (block per band; bands of ~4096 px keep
+// every block short, large objects are spread over many CUs).  Sums are combined with integer atomics
+// (exact, order-independent).
 // sums[s*PSEG_NSUMS + k]: 0 N, 1 sum r, 2 sum c, 3 sum r^2, 4 sum c^2, 5 sum r*c, 6 min I, 7 max I, 8 sum I,
 //   9 filled area, 10..12 perimeter code counts (weight 1, sqrt2, (1+sqrt2)/2), 13 euler, 14 convex area
-__global__ __launch_bounds__(256) void k_crops_sums(SegState S, const int32_t *geo, const long long *crop_off,
-                                                    const long long *bits_off, const uint32_t *maskbits,
-                                                    const uint8_t *cleaned, const uint8_t *raw, uint8_t *c_raw,
-                                                    uint8_t *c_masked, uint8_t *c_mask, long long *sums)
+__global__ __launch_bounds__(256) void k_crops_sums(SegState S, int n_saved, const int32_t *geo, const long long *crop_off,
+                                                    const long long *bits_off, const long long *band_off,
+                                                    const uint32_t *maskbits, const uint8_t *cleaned, const uint8_t *raw,
+                                                    uint8_t *c_raw, uint8_t *c_masked, uint8_t *c_mask, long long *sums)
 {
-    __shared__ unsigned long long sh[4];
-    __shared__ uint32_t shmm[2][4];
-    int s = blockIdx.x;
+    int lo = 0, hi = n_saved;                             // object s with band_off[s] <= blockIdx.x < band_off[s+1]
+    const long long bid = blockIdx.x;
+    while (hi - lo > 1) { int m = (lo + hi) >> 1; if (band_off[m] <= bid) lo = m; else hi = m; }
+    const int s = lo;
     const int32_t *o = geo + 8 * (size_t)s;
-    int f = o[0], bx = o[1], by = o[2], w = o[3], h = o[4], wpr = o[6];
+    const int f = o[0], bx = o[1], by = o[2], w = o[3], h = o[4], wpr = o[6];
+    const int rpb = crop_rows_per_band(w);
+    const int r0 = (int)(bid - band_off[s]) * rpb, r1 = (r0 + rpb < h) ? r0 + rpb : h;
     const uint32_t *mb = maskbits + bits_off[s];
-    size_t P = (size_t)S.H * S.W;
+    const size_t P = (size_t)S.H * S.W;
     const uint8_t *cl = cleaned + (size_t)f * P, *rw = raw + (size_t)f * P;
-    long long off = crop_off[s];
+    const long long off = crop_off[s];
     unsigned long long a[7] = {0, 0, 0, 0, 0, 0, 0};
     uint32_t imin = 255, imax = 0;
-    int np = w * h;
-    for (int p = threadIdx.x; p < np; p += blockDim.x) {
-        int yy = p / w, xx = p - yy * w;
+    const int np = (r1 - r0) * w;
+    const float rcp = 1.0f / (float)w;
+    for (int p = threadIdx.x; p < np; p += 256) {
+        int yy = (int)((float)p * rcp);                   // p / w, corrected below (p < 2^24)
+        int xx = p - yy * w;
+        if (xx < 0) { yy--; xx += w; } else if (xx >= w) { yy++; xx -= w; }
+        yy += r0;
         uint32_t bit = (mb[yy * wpr + (xx >> 5)] >> (xx & 31)) & 1u;
         size_t gi = (size_t)(by + yy) * S.W + bx + xx;
+        long long q = off + (long long)yy * w + xx;
         uint8_t cv = cl[gi];
-        c_raw[off + p] = rw[gi];
-        c_mask[off + p] = bit ? 255 : 0;
-        c_masked[off + p] = bit ? cv : 255;
+        c_raw[q] = rw[gi];
+        c_mask[q] = bit ? 255 : 0;
+        c_masked[q] = bit ? cv : 255;
         if (bit) {
             a[0] += 1; a[1] += yy; a[2] += xx;
             a[3] += (unsigned long long)yy * yy; a[4] += (unsigned long long)xx * xx; a[5] += (unsigned long long)yy * xx;
@@ -649,22 +702,23 @@ __global__ __launch_bounds__(256) void k_crops_sums(SegState S, const int32_t *g
             imin = cv < imin ? cv : imin; imax = cv > imax ? cv : imax;
         }
     }
-    unsigned long long tot[7];
-    for (int k = 0; k < 7; k++) tot[k] = block_sum_u64(a[k], sh);
+    for (int k = 0; k < 7; k++) a[k] = wave_sum_u64(a[k]);
     for (int o2 = 32; o2 > 0; o2 >>= 1) {
         uint32_t t0 = __shfl_down(imin, o2, 64), t1 = __shfl_down(imax, o2, 64);
         imin = t0 < imin ? t0 : imin; imax = t1 > imax ? t1 : imax;
     }
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) { shmm[0][threadIdx.x >> 6] = imin; shmm[1][threadIdx.x >> 6] = imax; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        long long *q = sums + (size_t)s * PSEG_NSUMS;
-        uint32_t mn = 255, mx = 0;
-        for (int k = 0; k < 4; k++) { mn = shmm[0][k] < mn ? shmm[0][k] : mn; mx = shmm[1][k] > mx ? shmm[1][k] : mx; }
-        q[0] = (long long)tot[0]; q[1] = (long long)tot[1]; q[2] = (long long)tot[2]; q[3] = (long long)tot[3];
-        q[4] = (long long)tot[4]; q[5] = (long long)tot[5]; q[6] = mn; q[7] = mx; q[8] = (long long)tot[6];
+    if ((threadIdx.x & 63) == 0 && a[0]) {
+        unsigned long long *q = (unsigned long long *)(sums + (size_t)s * PSEG_NSUMS);
+        atomicAdd(&q[0], a[0]); atomicAdd(&q[1], a[1]); atomicAdd(&q[2], a[2]); atomicAdd(&q[3], a[3]);
+        atomicAdd(&q[4], a[4]); atomicAdd(&q[5], a[5]); atomicAdd(&q[8], a[6]);
+        atomicMin((long long *)&q[6], (long long)imin); atomicMax((long long *)&q[7], (long long)imax);
     }
+}
+__global__ void k_init_sums(long long *sums, int n_saved)
+{
+    size_t g = GTID;
+    if (g >= (size_t)n_saved * PSEG_NSUMS) return;
+    sums[g] = (g % PSEG_NSUMS == 6) ? 255 : 0;             // min intensity starts at 255
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -703,7 +757,7 @@ extern "C" int pseg_destroy(pseg_ctx *ctx)
                       &ctx->bg_parent, &ctx->bg_left, &ctx->minx, &ctx->maxx, &ctx->miny, &ctx->maxy, &ctx->area2,
                       &ctx->extrank, &ctx->keptrank, &ctx->savedrank, &ctx->objlabel, &ctx->objflag, &ctx->rows,
                       &ctx->saved_row, &ctx->saved_geo, &ctx->crop_off, &ctx->bits_off, &ctx->maskbits, &ctx->sums,
-                      &ctx->crops_raw, &ctx->crops_masked, &ctx->crops_mask, &ctx->totals, &ctx->bounds};
+                      &ctx->crops_raw, &ctx->crops_masked, &ctx->crops_mask, &ctx->totals, &ctx->bounds, &ctx->band_off};
     for (DevBuf *b : bufs) if (b->p) hipFree(b->p);
     for (auto &e : ctx->ev) if (e) hipEventDestroy(e);
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
@@ -839,7 +893,7 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
     HIPCHK(hipEventRecord(ctx->ev[2], st));
     if (mask) {
         HIPCHK(hipMemsetAsync(ctx->maskcnt.p, 0, 8, st));
-        hipLaunchKernelGGL(k_mask_count, dim3(nblocks(P / 8)), dim3(256), 0, st, mask, P, (unsigned long long *)ctx->maskcnt.p);
+        hipLaunchKernelGGL(k_mask_count, dim3(256), dim3(256), 0, st, mask, P, (unsigned long long *)ctx->maskcnt.p);
     }
     HIPCHK(hipMemsetAsync(S.rowcnt, 0, (size_t)n * H * 4, st));
     size_t nwords = (size_t)n * H * WW;
@@ -882,27 +936,14 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
     hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(64), 0, st, (const uint32_t *)(ftot3 + 1), rowbase, n, 3, 1);
     hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(64), 0, st, (const uint32_t *)(ftot3 + 2), savedbase, n, 3, 1);
     HIPCHK(hipGetLastError());
-    // host copies of the per-frame tables
-    uint32_t *h_ft = ctx->h_tmp.as<uint32_t>((size_t)n * 8 + 16);
-    HIPCHK(hipMemcpyAsync(h_ft, ftot3, ((size_t)3 * n + 2 * (n + 1)) * 4, hipMemcpyDeviceToHost, st));
-    std::vector<uint64_t> fs((size_t)n * 4);
-    uint64_t h_maskcnt = (uint64_t)P;
-    HIPCHK(hipMemcpyAsync(fs.data(), ctx->fsums.p, (size_t)n * 4 * 8, hipMemcpyDeviceToHost, st));
-    if (mask) HIPCHK(hipMemcpyAsync(&h_maskcnt, ctx->maskcnt.p, 8, hipMemcpyDeviceToHost, st));
-    std::vector<uint8_t> hvalid(n);
-    HIPCHK(hipMemcpyAsync(hvalid.data(), ctx->valid_dev.p, n, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    const uint32_t *h_ftot3 = h_ft, *h_rowbase = h_ft + 3 * (size_t)n, *h_savedbase = h_rowbase + (n + 1);
-    const int n_rows = (int)h_rowbase[n], n_saved = (int)h_savedbase[n];
-
-    // rows
-    const size_t rcap = (size_t)(n_rows > 0 ? n_rows : 1), scap = (size_t)(n_saved > 0 ? n_saved : 1);
+    // rows: one per kept object; n_rows <= external roots <= nfg bounds the buffers without a host round trip
+    const size_t rcap = cap, scap = cap;
     ENSURE(ctx->rows, rcap * 10 * 4);
     ENSURE(ctx->saved_row, scap * 4);
-    ENSURE(ctx->saved_geo, scap * 8 * 4 + scap * 2 * 8);
+    ENSURE(ctx->saved_geo, scap * 8 * 4 + scap * 3 * 8);
     ENSURE(ctx->crop_off, (scap + 1) * 8);
     ENSURE(ctx->bits_off, (scap + 1) * 8);
-    ENSURE(ctx->sums, scap * PSEG_NSUMS * 8);
+    ENSURE(ctx->band_off, (scap + 1) * 8);
     RowsDev R;
     {
         int32_t *b = (int32_t *)ctx->rows.p;
@@ -912,35 +953,48 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
     int32_t *saved_row = (int32_t *)ctx->saved_row.p;
     int32_t *geo = (int32_t *)ctx->saved_geo.p;
     unsigned long long *sz = (unsigned long long *)(geo + 8 * scap);
+    long long *totals = (long long *)ctx->totals.p;
     if (nfg > 0) {
         hipLaunchKernelGGL(k_emit, dim3(nblocks(nfg)), dim3(256), 0, st, S, nfg, min_seg, min_save, (const uint32_t *)ftot3,
                            (const uint32_t *)rowbase, (const uint32_t *)savedbase, R, objlabel, objflag, saved_row);
+        hipLaunchKernelGGL(k_saved_geo, dim3(nblocks(nfg)), dim3(256), 0, st, (const uint32_t *)(savedbase + n),
+                           (const int32_t *)saved_row, R, geo, sz);
     }
+    hipLaunchKernelGGL(k_scan_sizes, dim3(1), dim3(1024), 0, st, (const unsigned long long *)sz, (const uint32_t *)(savedbase + n),
+                       (long long *)ctx->crop_off.p, (long long *)ctx->bits_off.p, (long long *)ctx->band_off.p, totals);
     HIPCHK(hipGetLastError());
+    // per-frame tables and totals to the host; the label map is written while the host waits for them
+    uint32_t *h_ft = ctx->h_tmp.as<uint32_t>((size_t)n * 8 + 16);
+    HIPCHK(hipMemcpyAsync(h_ft, ftot3, ((size_t)3 * n + 2 * (n + 1)) * 4, hipMemcpyDeviceToHost, st));
+    std::vector<uint64_t> fs((size_t)n * 4);
+    uint64_t h_maskcnt = (uint64_t)P;
+    HIPCHK(hipMemcpyAsync(fs.data(), ctx->fsums.p, (size_t)n * 4 * 8, hipMemcpyDeviceToHost, st));
+    if (mask) HIPCHK(hipMemcpyAsync(&h_maskcnt, ctx->maskcnt.p, 8, hipMemcpyDeviceToHost, st));
+    std::vector<uint8_t> hvalid(n);
+    HIPCHK(hipMemcpyAsync(hvalid.data(), ctx->valid_dev.p, n, hipMemcpyDeviceToHost, st));
+    long long h_tot[3] = {0, 0, 0};
+    HIPCHK(hipMemcpyAsync(h_tot, totals, 3 * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipEventRecord(ctx->ev[3], st));
     if (labels) {
-        HIPCHK(hipMemsetAsync(labels, 0, (size_t)n * P * 4, st));
-        if (nfg > 0) hipLaunchKernelGGL(k_label_runs, dim3(nblocks(nfg)), dim3(256), 0, st, S, nfg, (const int32_t *)objlabel, labels);
+        hipLaunchKernelGGL(k_label_fill, dim3(nblocks(P / 4), n), dim3(256), 0, st, S, (const int32_t *)objlabel, labels);
+        HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(ctx->ev[4], st));
-    long long h_tot[2] = {0, 0};
+    HIPCHK(hipEventSynchronize(ctx->ev[3]));
+    const uint32_t *h_ftot3 = h_ft, *h_rowbase = h_ft + 3 * (size_t)n, *h_savedbase = h_rowbase + (n + 1);
+    const int n_rows = (int)h_rowbase[n], n_saved = (int)h_savedbase[n];
     if (n_saved > 0) {
-        hipLaunchKernelGGL(k_saved_geo, dim3(nblocks(n_saved)), dim3(256), 0, st, n_saved, (const int32_t *)saved_row, R, geo, sz);
-        hipLaunchKernelGGL(k_scan_sizes, dim3(1), dim3(64), 0, st, (const unsigned long long *)sz, n_saved,
-                           (long long *)ctx->crop_off.p, (long long *)ctx->bits_off.p);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(&h_tot[0], (long long *)ctx->crop_off.p + n_saved, 8, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipMemcpyAsync(&h_tot[1], (long long *)ctx->bits_off.p + n_saved, 8, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
+        if (h_tot[2] > 0x7fffffffLL) return fail(ctx, PSEG_ERR_CAPACITY, "too many crop bands");
         ENSURE(ctx->crops_raw, (size_t)h_tot[0]); ENSURE(ctx->crops_masked, (size_t)h_tot[0]); ENSURE(ctx->crops_mask, (size_t)h_tot[0]);
         ENSURE(ctx->maskbits, (size_t)h_tot[1] * 4);
-        HIPCHK(hipMemsetAsync(ctx->sums.p, 0, (size_t)n_saved * PSEG_NSUMS * 8, st));
+        ENSURE(ctx->sums, (size_t)n_saved * PSEG_NSUMS * 8);
+        hipLaunchKernelGGL(k_init_sums, dim3(nblocks((size_t)n_saved * PSEG_NSUMS)), dim3(256), 0, st, (long long *)ctx->sums.p, n_saved);
         hipLaunchKernelGGL(k_build_masks, dim3(n_saved), dim3(256), 0, st, S, (const int32_t *)geo, (const long long *)ctx->bits_off.p,
                            (const int32_t *)objflag, (uint32_t *)ctx->maskbits.p);
-        hipLaunchKernelGGL(k_crops_sums, dim3(n_saved), dim3(256), 0, st, S, (const int32_t *)geo, (const long long *)ctx->crop_off.p,
-                           (const long long *)ctx->bits_off.p, (const uint32_t *)ctx->maskbits.p, cleaned, raw,
-                           (uint8_t *)ctx->crops_raw.p, (uint8_t *)ctx->crops_masked.p, (uint8_t *)ctx->crops_mask.p,
-                           (long long *)ctx->sums.p);
+        hipLaunchKernelGGL(k_crops_sums, dim3((unsigned)h_tot[2]), dim3(256), 0, st, S, n_saved, (const int32_t *)geo,
+                           (const long long *)ctx->crop_off.p, (const long long *)ctx->bits_off.p, (const long long *)ctx->band_off.p,
+                           (const uint32_t *)ctx->maskbits.p, cleaned, raw, (uint8_t *)ctx->crops_raw.p,
+                           (uint8_t *)ctx->crops_masked.p, (uint8_t *)ctx->crops_mask.p, (long long *)ctx->sums.p);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(ctx->ev[5], st));
@@ -948,12 +1002,15 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
     ctx->n_saved = n_saved;
 
     // ---- results to the host ----
-    int32_t *hrows = ctx->h_rows.as<int32_t>(rcap * 10);
-    int32_t *h_saved_row = ctx->h_saved_row.as<int32_t>(scap);
-    int64_t *h_crop_off = ctx->h_crop_off.as<int64_t>(scap + 1);
-    int64_t *h_sums = ctx->h_sums.as<int64_t>(scap * PSEG_NSUMS);
+    const size_t hr = (size_t)(n_rows > 0 ? n_rows : 1), hs = (size_t)(n_saved > 0 ? n_saved : 1);
+    int32_t *hrows = ctx->h_rows.as<int32_t>(hr * 10);
+    int32_t *h_saved_row = ctx->h_saved_row.as<int32_t>(hs);
+    int64_t *h_crop_off = ctx->h_crop_off.as<int64_t>(hs + 1);
+    int64_t *h_sums = ctx->h_sums.as<int64_t>(hs * PSEG_NSUMS);
     h_crop_off[0] = 0;
-    if (n_rows > 0) HIPCHK(hipMemcpyAsync(hrows, ctx->rows.p, rcap * 10 * 4, hipMemcpyDeviceToHost, st));
+    if (n_rows > 0)
+        for (int k = 0; k < 10; k++)
+            HIPCHK(hipMemcpyAsync(hrows + k * hr, (int32_t *)ctx->rows.p + k * rcap, (size_t)n_rows * 4, hipMemcpyDeviceToHost, st));
     if (n_saved > 0) {
         HIPCHK(hipMemcpyAsync(h_saved_row, saved_row, (size_t)n_saved * 4, hipMemcpyDeviceToHost, st));
         HIPCHK(hipMemcpyAsync(h_crop_off, ctx->crop_off.p, (size_t)(n_saved + 1) * 8, hipMemcpyDeviceToHost, st));
@@ -975,19 +1032,19 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
         h_fv[f] = hvalid[f];
         finish_meanstd(fs.data() + 4 * f + 2, (double)h_maskcnt, &h_mean[f], &h_std[f]);
     }
-    double *h_area = ctx->h_area.as<double>(rcap);
-    uint8_t *h_s8 = ctx->h_saved8.as<uint8_t>(rcap);
-    double *h_props = ctx->h_props.as<double>(rcap * PSEG_NPROPS);
+    double *h_area = ctx->h_area.as<double>(hr);
+    uint8_t *h_s8 = ctx->h_saved8.as<uint8_t>(hr);
+    double *h_props = ctx->h_props.as<double>(hr * PSEG_NPROPS);
     for (int i = 0; i < n_rows; i++) {
-        h_area[i] = 0.5 * (double)hrows[3 * rcap + i];
-        h_s8[i] = (uint8_t)hrows[8 * rcap + i];
+        h_area[i] = 0.5 * (double)hrows[3 * hr + i];
+        h_s8[i] = (uint8_t)hrows[8 * hr + i];
         for (int k = 0; k < PSEG_NPROPS; k++) h_props[(size_t)i * PSEG_NPROPS + k] = NAN;
     }
     for (int s = 0; s < n_saved; s++) {
         int i = h_saved_row[s];
         const int64_t *q = h_sums + (size_t)s * PSEG_NSUMS;
         double *p = h_props + (size_t)i * PSEG_NPROPS;
-        const double w = hrows[6 * rcap + i], h = hrows[7 * rcap + i];
+        const double w = hrows[6 * hr + i], h = hrows[7 * hr + i];
         const double N = (double)q[0];
         const double cr = q[1] / N, cc = q[2] / N;
         const double mu20 = q[3] / N - cr * cr, mu02 = q[4] / N - cc * cc, mu11 = q[5] / N - cr * cc;
@@ -1016,8 +1073,8 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
         out->n_frames = n; out->n_rows = n_rows; out->n_saved = n_saved; out->crop_bytes = ctx->crop_bytes;
         out->frame_row_offset = h_fro; out->frame_n_contours = h_fnc; out->frame_valid = h_fv;
         out->frame_mean = h_mean; out->frame_std = h_std;
-        out->row_frame = hrows; out->row_c = hrows + rcap; out->row_label = hrows + 2 * rcap; out->row_area = h_area;
-        out->row_x = hrows + 4 * rcap; out->row_y = hrows + 5 * rcap; out->row_w = hrows + 6 * rcap; out->row_h = hrows + 7 * rcap;
+        out->row_frame = hrows; out->row_c = hrows + hr; out->row_label = hrows + 2 * hr; out->row_area = h_area;
+        out->row_x = hrows + 4 * hr; out->row_y = hrows + 5 * hr; out->row_w = hrows + 6 * hr; out->row_h = hrows + 7 * hr;
         out->row_saved = h_s8; out->row_props = h_props; out->saved_row = h_saved_row; out->crop_offset = h_crop_off;
         out->sums = h_sums;
         out->crops_raw_dev = (const uint8_t *)ctx->crops_raw.p; out->crops_masked_dev = (const uint8_t *)ctx->crops_masked.p;

@@ -65,6 +65,7 @@ struct SegState {
 PSEG_HD int seg_rowstart(const SegState &S, int f, int y) { return (int)(S.framebase[f] + S.rowoff[f * (S.H + 1) + y]); }
 PSEG_HD int seg_rowcount(const SegState &S, int f, int y) { return (int)(S.rowoff[f * (S.H + 1) + y + 1] - S.rowoff[f * (S.H + 1) + y]); }
 PSEG_HD int seg_bgbase(const SegState &S, int f, int y) { return seg_rowstart(S, f, y) + f * S.H + y; }
+PSEG_HD int seg_b0(const SegState &S, int f) { return (int)S.framebase[f] + f * S.H; }   // smallest background index of frame f
 PSEG_HD int run_xs(const SegState &S, int r) { return (int)(S.run_x[r] & 0xffffu); }
 PSEG_HD int run_xe(const SegState &S, int r) { return (int)(S.run_x[r] >> 16); }
 
@@ -100,9 +101,11 @@ PSEG_HD void fill_runs_body(const SegState &S, size_t g)
     if (!st) return;
     int idx = seg_rowstart(S, f, y);
     size_t g0 = g - w;
-    for (int k = 0; k < w; k++) {
+    uint64_t carry = 0;                                   // top bit of the previous word
+    for (int k = 0; k < w; k++) {                         // independent loads: the compiler can batch them
         uint64_t u = S.bits[g0 + k];
-        if (u) idx += PSEG_POPC64(seg_starts(S, g0 + k, k, u));
+        idx += PSEG_POPC64(u & ~((u << 1) | carry));
+        carry = u >> 63;
     }
     while (st) {
         int s = PSEG_CTZ64(st);
@@ -176,8 +179,9 @@ PSEG_HD void bg_union_elem(const SegState &S, int f, int y, int j)
     int a = j == 0 ? -1 : run_xe(S, rs + j - 1) + 1;
     int e = j == n ? S.W : run_xs(S, rs + j) - 1;
     S.bg_left[b] = j == 0 ? -1 : rs + j - 1;
-    if (j == n && n > 0) uf_union(S.bg_parent, b, bb);
-    if ((y == 0 || y == S.H - 1) && j > 0) uf_union(S.bg_parent, b, bb);
+    // gaps that touch the zero padding (first / last gap of a row, every gap of the first / last row)
+    // are linked straight to the frame's smallest background index: no chains through the rows
+    if (j == 0 || j == n || y == 0 || y == S.H - 1) uf_union(S.bg_parent, b, seg_b0(S, f));
     if (y == 0) return;
     int ps = seg_rowstart(S, f, y - 1), pn = rs - ps, pb = ps + f * S.H + (y - 1);
     // first gap j' of the previous row whose right end (xs_{j'} - 1, or W for j' = pn) >= a
@@ -204,7 +208,6 @@ PSEG_HD void bg_union_body(const SegState &S, int t, int nfg)
 PSEG_HD void flatten_body(int32_t *parent, int i) { parent[i] = uf_find(parent, i); }
 
 // ---- 5. enclosure tree: external ancestor of every run ---------------------------------------
-PSEG_HD int seg_b0(const SegState &S, int f) { return (int)S.framebase[f] + f * S.H; }
 PSEG_HD void resolve_ext_body(const SegState &S, int r)
 {
     int R = S.fg_parent[r];
@@ -229,10 +232,12 @@ PSEG_HD void bbox_body(const SegState &S, int r)
 {
     int E = S.ext[r];
     int y = (int)(S.run_fy[r] & 0xffffu);
-    PSEG_ATOMIC_MIN(&S.minx[E], run_xs(S, r));
-    PSEG_ATOMIC_MAX(&S.maxx[E], run_xe(S, r));
-    PSEG_ATOMIC_MIN(&S.miny[E], y);
-    PSEG_ATOMIC_MAX(&S.maxy[E], y);
+    int xs = run_xs(S, r), xe = run_xe(S, r);
+    // monotone values: a (possibly stale) read that already satisfies the bound makes the atomic redundant
+    if (xs < S.minx[E]) PSEG_ATOMIC_MIN(&S.minx[E], xs);
+    if (xe > S.maxx[E]) PSEG_ATOMIC_MAX(&S.maxx[E], xe);
+    if (y < S.miny[E]) PSEG_ATOMIC_MIN(&S.miny[E], y);
+    if (y > S.maxy[E]) PSEG_ATOMIC_MAX(&S.maxy[E], y);
 }
 
 // ---- spans of the hole-filled objects in one row ------------------------------------------------
