@@ -53,7 +53,7 @@ struct pseg_ctx {
         keptrank, savedrank, objlabel, objflag;
     DevBuf rows, saved_row, saved_geo, crop_off, bits_off, maskbits, sums, crops_raw, crops_masked, crops_mask, totals;
     bool have_bits = false;       // threshold plane + masked sums already produced by the bg kernel
-    DevBuf bounds, band_off;
+    DevBuf bounds, band_off, trash;
     int bounds_n = -1, bounds_chunks = -1;
     int bg_chunks = 1;            // time chunks of the streaming background kernel (PSEG_BG_CHUNKS)
     bool force_generic = false;   // PSEG_BG_GENERIC=1: use the 12x-read reference kernel (debug / cross-check)
@@ -231,70 +231,86 @@ __device__ __forceinline__ uint2 ld_stream(const uint8_t *p)
     return make_uint2(v.x, v.y);
 }
 struct BgEmit {
-    uint8_t *cleaned; uint8_t *bits8; uint4 *partials; size_t P, strip; uint2 inm; uint32_t kthr; int thr_hi; uint32_t nwaves, wave;
+    uint8_t *cleaned, *bits8; uint4 *partials;              // real outputs
+    uint8_t *t_cleaned, *t_bits8; uint4 *t_partials;        // trash rows: where a disabled step stores (keeps the loop branch-free)
+    size_t P, strip; uint2 inm; uint32_t kthr, thr_en; int thr_hi; uint32_t nwaves, wave;
     uint32_t act;          // 0xffffffff for strips inside the frame, 0 for the padding lanes of the last wave
 };
 // bit 7 of every byte of x that is >= t (1 <= t <= 255), kt = t (t <= 128) or t-128, replicated
 __device__ __forceinline__ uint32_t bytes_ge(uint32_t x, uint32_t kt, int hi)
 {
     uint32_t y = ((x & 0x7f7f7f7fu) | 0x80808080u) - kt;
-    return (hi ? (y & x) : (y | x)) & 0x80808080u;
+    uint32_t hm = hi ? 0xffffffffu : 0u;                    // branch-free select between (y & x) and (y | x)
+    return (((y & x) & hm) | ((y | x) & ~hm)) & 0x80808080u;
 }
 __device__ __forceinline__ uint32_t gather4(uint32_t r)     // bits 7,15,23,31 -> bits 0..3
 {
     r >>= 7; r |= r >> 7; r |= r >> 14;
     return r & 0xfu;
 }
-__device__ __forceinline__ void bg_emit(const BgEmit &E, uint2 img, Px8 bg, int s)
+// frame s: cleaned = 255 - |img - bg| (bg_correction.py:80-81), the four sums and the threshold bits
+// (detection.py:178-202).  en is wave-uniform; a disabled call stores into the trash rows.
+__device__ __forceinline__ void bg_emit(const BgEmit &E, uint2 img, Px8 bg, int s, bool en)
 {
     Px8 c = px_split(img);
     uint32_t de0 = pksub(pkmax(c.e0, bg.e0), pkmin(c.e0, bg.e0)), do0 = pksub(pkmax(c.o0, bg.o0), pkmin(c.o0, bg.o0));
     uint32_t de1 = pksub(pkmax(c.e1, bg.e1), pkmin(c.e1, bg.e1)), do1 = pksub(pkmax(c.o1, bg.o1), pkmin(c.o1, bg.o1));
-    uint2 corr = make_uint2(__builtin_amdgcn_perm(do0, de0, 0x06020400), __builtin_amdgcn_perm(do1, de1, 0x06020400));   // :80
-    if (E.act) *(uint2 *)(E.cleaned + (size_t)s * E.P + E.strip * 8) = make_uint2(~corr.x, ~corr.y);                 // :81
+    uint2 corr = make_uint2(__builtin_amdgcn_perm(do0, de0, 0x06020400), __builtin_amdgcn_perm(do1, de1, 0x06020400));
+    // every store is unconditional (disabled steps and padding lanes write to the trash rows): with no
+    // branch in the loop body the compiler counts the outstanding loads exactly (vmcnt counts stores too)
+    const bool real = en && E.act;
+    uint8_t *pc = real ? E.cleaned + (size_t)s * E.P : E.t_cleaned;
+    uint8_t *pb = real ? E.bits8 + (size_t)s * (E.P / 8) : E.t_bits8;
+    uint4 *pp = en ? E.partials + (size_t)s * E.nwaves : E.t_partials;
+    *(uint2 *)(pc + E.strip * 8) = make_uint2(~corr.x, ~corr.y);
     uint2 cm = make_uint2(corr.x & E.inm.x, corr.y & E.inm.y);
     img.x &= E.act; img.y &= E.act;
     uint32_t s0 = __builtin_amdgcn_sad_u8(img.x, 0u, __builtin_amdgcn_sad_u8(img.y, 0u, 0u));
     uint32_t s1 = __builtin_amdgcn_udot4(img.x, img.x, __builtin_amdgcn_udot4(img.y, img.y, 0u, false), false);
     uint32_t s2 = __builtin_amdgcn_sad_u8(cm.x, 0u, __builtin_amdgcn_sad_u8(cm.y, 0u, 0u));
     uint32_t s3 = __builtin_amdgcn_udot4(cm.x, cm.x, __builtin_amdgcn_udot4(cm.y, cm.y, 0u, false), false);
-    uint32_t b = 0;
-    if (E.kthr) b = gather4(bytes_ge(cm.x, E.kthr, E.thr_hi)) | (gather4(bytes_ge(cm.y, E.kthr, E.thr_hi)) << 4);
-    if (E.act) E.bits8[(size_t)s * (E.P / 8) + E.strip] = (uint8_t)b;
+    uint32_t b = (gather4(bytes_ge(cm.x, E.kthr, E.thr_hi)) | (gather4(bytes_ge(cm.y, E.kthr, E.thr_hi)) << 4)) & E.thr_en;
+    pb[E.strip] = (uint8_t)b;
     s0 = wave_sum63(s0); s1 = wave_sum63(s1); s2 = wave_sum63(s2); s3 = wave_sum63(s3);
-    if ((threadIdx.x & 63) == 63) E.partials[(size_t)s * E.nwaves + E.wave] = make_uint4(s0, s1, s2, s3);
+    if ((threadIdx.x & 63) == 63) pp[E.wave] = make_uint4(s0, s1, s2, s3);
 }
 
-struct BgRing {
-    uint2 raw[16];
-    Px8 mp, t2[2], t4[4], t8[4];
+// Per-thread state.  The 12-frame history of raw pixels lives in an LDS ring (dynamic slot index,
+// private to the thread: no barriers); the sparse table and 4 prefetched frames live in registers
+// with compile-time phases (loop unrolled by 4).
+struct BgRegs {
+    uint2 pf[4];           // frames k .. k+3 (pf[PH] is the frame of the current step)
+    uint2 prev;            // frame k-1
+    Px8 mp, t2[2], t4[4], t8[4], last;
 };
+#define BG_SLOTS 16
 template <int PH>
-__device__ __forceinline__ void bg_step(BgRing &R, const BgEmit &E, const uint8_t *__restrict__ src, int k, int a, int kend, int n)
+__device__ __forceinline__ void bg_step(BgRegs &R, uint2 *ring, const BgEmit &E, const uint8_t *__restrict__ src, int k, int a,
+                                        int kend, int n)
 {
-    if (k < a || k > kend) return;
-    if (k + 4 <= kend) R.raw[(PH + 4) & 15] = ld_stream(src + (size_t)(k + 4) * E.P);
-    Px8 ce = px_split(R.raw[PH]);
-    if (k > a) {
-        Px8 m = px_min(px_split(R.raw[(PH + 15) & 15]), ce);   // previous frame re-split: 4 ops instead of 4 live registers
-        Px8 t2 = px_max(m, R.mp); R.mp = m;
-        Px8 t4 = px_max(t2, R.t2[(PH + 1) & 1]); R.t2[(PH + 1) & 1] = t2;
-        Px8 t8 = px_max(t4, R.t4[(PH + 3) & 3]); R.t4[(PH + 3) & 3] = t4;
-        Px8 t11 = px_max(t8, R.t8[PH & 3]); R.t8[(PH + 3) & 3] = t8;
-        if (k < n - 1) {
-            if (k - 11 >= a) bg_emit(E, R.raw[(PH + 5) & 15], t11, k - 11);
-        } else {                                            // k == n-1: the last 12 frames share this background;
-#pragma unroll 1                                            // they are re-read (cache hits) to keep the ring indices static
-            for (int i = n - 12; i < n; i++) bg_emit(E, ld_stream(src + (size_t)i * E.P), t11, i);
-        }
-    }
+    const uint2 cur = R.pf[PH];
+    int kn = k + 4 <= kend ? k + 4 : kend;                  // clamped prefetch: always a valid frame
+    R.pf[PH] = ld_stream(src + (size_t)kn * E.P);
+    ring[(k & (BG_SLOTS - 1)) * 256] = cur;
+    const uint2 old = ring[((k - 11) & (BG_SLOTS - 1)) * 256];   // frame k-11 (zeros during warm-up)
+    Px8 m = px_min(px_split(R.prev), px_split(cur));        // pair minimum m[k-1]
+    if (k == a) m = Px8{0, 0, 0, 0};                         // no pair yet at the first frame of the chunk
+    R.prev = cur;
+    Px8 t2 = px_max(m, R.mp); R.mp = m;
+    Px8 t4 = px_max(t2, R.t2[(PH + 1) & 1]); R.t2[(PH + 1) & 1] = t2;
+    Px8 t8 = px_max(t4, R.t4[(PH + 3) & 3]); R.t4[(PH + 3) & 3] = t4;
+    Px8 t11 = px_max(t8, R.t8[PH & 3]); R.t8[(PH + 3) & 3] = t8;
+    R.last = t11;
+    bg_emit(E, old, t11, k - 11, k - 11 >= a && k < n - 1);
 }
 
 // grid = (ceil(P/2048), chunks); chunk c emits frames [bounds[c], bounds[c+1])
 __global__ __launch_bounds__(256, 4) void k_bg_stream(const uint8_t *__restrict__ frames, int n, size_t P, uint8_t *__restrict__ cleaned,
-                                                   const uint8_t *__restrict__ mask, int thr, uint8_t *__restrict__ bits8,
-                                                   uint4 *__restrict__ partials, const int *__restrict__ bounds)
+                                                      const uint8_t *__restrict__ mask, int thr, uint8_t *__restrict__ bits8,
+                                                      uint4 *__restrict__ partials, const int *__restrict__ bounds,
+                                                      uint8_t *__restrict__ trash)
 {
+    __shared__ uint2 lds[BG_SLOTS * 256];
     size_t strip = (size_t)blockIdx.x * 256 + threadIdx.x;
     const bool act = strip * 8 < P;                         // padding lanes stay in the wave (DPP sums), load strip 0, store nothing
     if (!act) strip = 0;
@@ -302,46 +318,40 @@ __global__ __launch_bounds__(256, 4) void k_bg_stream(const uint8_t *__restrict_
     const int kend = (b == n) ? n - 1 : b + 10;
     BgEmit E;
     E.cleaned = cleaned; E.bits8 = bits8; E.partials = partials; E.P = P; E.strip = strip;
+    E.t_cleaned = trash; E.t_bits8 = trash + P; E.t_partials = (uint4 *)(trash + P + P / 8);
     E.inm = make_uint2(0xffffffffu, 0xffffffffu);
     if (mask) { uint2 m = *(const uint2 *)(mask + strip * 8); E.inm = make_uint2(eq255_4(m.x), eq255_4(m.y)); }
     E.act = act ? 0xffffffffu : 0u;
     E.inm.x &= E.act; E.inm.y &= E.act;
     int t1 = thr + 1;                                       // pixel > thr  <=>  pixel >= thr + 1
-    E.kthr = (t1 >= 1 && t1 <= 255) ? (uint32_t)(t1 <= 128 ? t1 : t1 - 128) * 0x01010101u : 0u;
+    E.thr_en = (t1 >= 1 && t1 <= 255) ? 0xffu : 0u;       // threshold outside 0..254: no pixel passes
+    E.kthr = E.thr_en ? (uint32_t)(t1 <= 128 ? t1 : t1 - 128) * 0x01010101u : 0x01010101u;
     E.thr_hi = t1 > 128;
     E.nwaves = gridDim.x * 4; E.wave = blockIdx.x * 4 + (threadIdx.x >> 6);
     const uint8_t *src = frames + strip * 8;
-    BgRing R;
+    uint2 *ring = lds + threadIdx.x;
+#pragma unroll
+    for (int q = 0; q < BG_SLOTS; q++) ring[q * 256] = make_uint2(0, 0);
+    BgRegs R;
     const Px8 z = {0, 0, 0, 0};
-    R.mp = z;
+    R.mp = z; R.last = z; R.prev = make_uint2(0, 0);
     for (int i = 0; i < 2; i++) R.t2[i] = z;
     for (int i = 0; i < 4; i++) { R.t4[i] = z; R.t8[i] = z; }
-    // phase of frame k is (k - kbase) & 15 with the chunk's last frame on phase 15
-    const int kbase = kend - 15 - 16 * ((kend - a) / 16);
-    {   // prologue: the first four frames of the chunk (their ring slots follow from the phase rule)
-        uint2 f0 = ld_stream(src + (size_t)a * P);
-        uint2 f1 = a + 1 <= kend ? ld_stream(src + (size_t)(a + 1) * P) : f0;
-        uint2 f2 = a + 2 <= kend ? ld_stream(src + (size_t)(a + 2) * P) : f0;
-        uint2 f3 = a + 3 <= kend ? ld_stream(src + (size_t)(a + 3) * P) : f0;
-        const int p0 = (a - kbase) & 15;
 #pragma unroll
-        for (int q = 0; q < 16; q++) {
-            if (q == p0) R.raw[q] = f0;
-            else if (q == ((p0 + 1) & 15)) R.raw[q] = f1;
-            else if (q == ((p0 + 2) & 15)) R.raw[q] = f2;
-            else if (q == ((p0 + 3) & 15)) R.raw[q] = f3;
-            else R.raw[q] = make_uint2(0, 0);
-        }
+    for (int i = 0; i < 4; i++) R.pf[i] = ld_stream(src + (size_t)(a + i <= kend ? a + i : kend) * P);
+    int k = a;
+    for (; k + 3 <= kend; k += 4) {                         // branch-free body: counted waits keep 4 loads in flight
+        bg_step<0>(R, ring, E, src, k, a, kend, n);
+        bg_step<1>(R, ring, E, src, k + 1, a, kend, n);
+        bg_step<2>(R, ring, E, src, k + 2, a, kend, n);
+        bg_step<3>(R, ring, E, src, k + 3, a, kend, n);
     }
-    for (int kb = kbase; kb <= kend; kb += 16) {
-        bg_step<0>(R, E, src, kb + 0, a, kend, n);   bg_step<1>(R, E, src, kb + 1, a, kend, n);
-        bg_step<2>(R, E, src, kb + 2, a, kend, n);   bg_step<3>(R, E, src, kb + 3, a, kend, n);
-        bg_step<4>(R, E, src, kb + 4, a, kend, n);   bg_step<5>(R, E, src, kb + 5, a, kend, n);
-        bg_step<6>(R, E, src, kb + 6, a, kend, n);   bg_step<7>(R, E, src, kb + 7, a, kend, n);
-        bg_step<8>(R, E, src, kb + 8, a, kend, n);   bg_step<9>(R, E, src, kb + 9, a, kend, n);
-        bg_step<10>(R, E, src, kb + 10, a, kend, n); bg_step<11>(R, E, src, kb + 11, a, kend, n);
-        bg_step<12>(R, E, src, kb + 12, a, kend, n); bg_step<13>(R, E, src, kb + 13, a, kend, n);
-        bg_step<14>(R, E, src, kb + 14, a, kend, n); bg_step<15>(R, E, src, kb + 15, a, kend, n);
+    if (k <= kend) bg_step<0>(R, ring, E, src, k, a, kend, n);
+    if (k + 1 <= kend) bg_step<1>(R, ring, E, src, k + 1, a, kend, n);
+    if (k + 2 <= kend) bg_step<2>(R, ring, E, src, k + 2, a, kend, n);
+    if (b == n) {                                           // the last 12 frames share bg[n-12] = T11 of the final step
+#pragma unroll 1
+        for (int i = n - 12; i < n; i++) bg_emit(E, ld_stream(src + (size_t)i * P), R.last, i, true);
     }
 }
 
@@ -757,7 +767,7 @@ extern "C" int pseg_destroy(pseg_ctx *ctx)
                       &ctx->bg_parent, &ctx->bg_left, &ctx->minx, &ctx->maxx, &ctx->miny, &ctx->maxy, &ctx->area2,
                       &ctx->extrank, &ctx->keptrank, &ctx->savedrank, &ctx->objlabel, &ctx->objflag, &ctx->rows,
                       &ctx->saved_row, &ctx->saved_geo, &ctx->crop_off, &ctx->bits_off, &ctx->maskbits, &ctx->sums,
-                      &ctx->crops_raw, &ctx->crops_masked, &ctx->crops_mask, &ctx->totals, &ctx->bounds, &ctx->band_off};
+                      &ctx->crops_raw, &ctx->crops_masked, &ctx->crops_mask, &ctx->totals, &ctx->bounds, &ctx->band_off, &ctx->trash};
     for (DevBuf *b : bufs) if (b->p) hipFree(b->p);
     for (auto &e : ctx->ev) if (e) hipEventDestroy(e);
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
@@ -801,6 +811,7 @@ static int run_bg(pseg_ctx *ctx, const uint8_t *frames, int n, int n_bg_imgs, co
     ENSURE(ctx->valid_dev, (size_t)n);
     int chunks = 1;
     if (stream) {
+        ENSURE(ctx->trash, P + P / 8 + (size_t)npart * 16 + 256);
         chunks = ctx->bg_chunks;
         if (chunks > n - 12) chunks = n - 12;
         if (chunks < 1) chunks = 1;
@@ -817,7 +828,7 @@ static int run_bg(pseg_ctx *ctx, const uint8_t *frames, int n, int n_bg_imgs, co
     HIPCHK(hipEventRecord(ctx->ev[0], ctx->stream));
     if (stream)
         hipLaunchKernelGGL(k_bg_stream, dim3(nblk, chunks), dim3(256), 0, ctx->stream, frames, n, P, cleaned, mask, thr,
-                           (uint8_t *)ctx->bits.p, (uint4 *)ctx->partials.p, (const int *)ctx->bounds.p);
+                           (uint8_t *)ctx->bits.p, (uint4 *)ctx->partials.p, (const int *)ctx->bounds.p, (uint8_t *)ctx->trash.p);
     else
         hipLaunchKernelGGL(k_bg_generic, dim3(nblk, n), dim3(256), 0, ctx->stream, frames, n, NW, P, cleaned, mask, thr,
                            (uint8_t *)ctx->bits.p, (uint32_t *)ctx->partials.p);
