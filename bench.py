@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--workload", default="pisco", choices=["pisco", "uvp5_dense"])
     ap.add_argument("--no-labels", action="store_true", help="streamed mode: label map not materialised (config #5)")
     ap.add_argument("--cpu-frames", type=int, default=13, help="frames of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--streams", type=int, default=2, help="contexts (own HIP stream + host thread each) that alternate batches")
     args = ap.parse_args()
 
     import torch
@@ -61,7 +62,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
 
-    seg = Segmenter(H, W, max_frames=BATCH, device=local_rank)
+    import queue
+    import threading
+    ns = max(1, args.streams)
+    segs = [Segmenter(H, W, max_frames=BATCH, device=local_rank) for _ in range(ns)]
+    seg = segs[0]
     mask = seg.disk_mask(1200)
     cfg = synth.CONFIGS[args.workload]
     nb = max(1, min(args.batches, args.steps + args.warmup))
@@ -70,32 +75,49 @@ def main():
     for b in range(nb):
         objs, off = synth.make_objects(BATCH, H, W, seed, frame0=b * BATCH, **cfg)
         stacks.append(seg.synth_frames(BATCH, seed, objs, off, frame0=b * BATCH))
-    cleaned = torch.empty((BATCH, H, W), dtype=torch.uint8, device=dev)
-    labels = None if args.no_labels else torch.empty((BATCH, H, W), dtype=torch.int32, device=dev)
+    cleaned = [torch.empty((BATCH, H, W), dtype=torch.uint8, device=dev) for _ in range(ns)]
+    labels = [None if args.no_labels else torch.empty((BATCH, H, W), dtype=torch.int32, device=dev) for _ in range(ns)]
 
     group_ms = {k: 0.0 for k in GROUP_NAMES}
     stats = dict(rows=0, saved=0, crop_bytes=0, contours=0)
+    lock = threading.Lock()
 
-    def step(i, timed):
-        _, _, _, tab = seg.process(stacks[i % nb], mask=mask, cleaned=cleaned, labels=labels)
-        if world > 1:
-            sharding.gather_tables(sharding.pack_table(tab, frame_base=(rank * nb + i % nb) * BATCH), device=dev)
+    def step(i, k, timed, out_q=None):
+        """one batch through the fused hot path on context k"""
+        _, _, _, tab = segs[k].process(stacks[i % nb], mask=mask, cleaned=cleaned[k], labels=labels[k])
+        if out_q is not None:
+            out_q.put((i, sharding.pack_table(tab, frame_base=(rank * nb + i % nb) * BATCH)))
         if timed:
-            for k in GROUP_NAMES:
-                group_ms[k] += seg.last_ms(k)
-            stats["rows"] += tab.n_rows
-            stats["saved"] += int(tab.saved.sum())
-            stats["crop_bytes"] += tab.crop_bytes
-            stats["contours"] += int(tab.frame_n_contours.sum())
+            with lock:
+                stats["rows"] += tab.n_rows
+                stats["saved"] += int(tab.saved.sum())
+                stats["crop_bytes"] += tab.crop_bytes
+                stats["contours"] += int(tab.frame_n_contours.sum())
 
-    for i in range(args.warmup):
-        step(i, False)
+    def run(first, count, timed):
+        """steps first..first+count-1, dealt round-robin to the contexts (one host thread each); the object
+        tables are gathered to rank 0 from the main thread, in step order, while later batches compute"""
+        out_q = queue.Queue() if world > 1 else None
+        ths = [threading.Thread(target=lambda k=k: [step(i, k, timed, out_q) for i in range(first + k, first + count, ns)])
+               for k in range(ns)]
+        for t in ths:
+            t.start()
+        if world > 1:
+            pending = {}
+            for want in range(first, first + count):
+                while want not in pending:
+                    i, blob = out_q.get()
+                    pending[i] = blob
+                sharding.gather_tables(pending.pop(want), device=dev)
+        for t in ths:
+            t.join()
+
+    run(0, args.warmup, False)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i, True)
+    run(args.warmup, args.steps, True)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -104,13 +126,20 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # kernel-group durations for the roofline: HIP events on the library's stream, one context alone on the GPU
+    # (with several contexts in flight the kernels of different batches overlap and share the bandwidth)
+    nprobe = min(4, args.steps)
+    for i in range(nprobe):
+        step(args.warmup + i, 0, False)
+        for k in GROUP_NAMES:
+            group_ms[k] += seg.last_ms(k)
 
     frames = args.steps * BATCH * world
     fps = frames / elapsed
     # dominant kernel group by device time (HIP events inside the library, on its own stream)
     dom = max(GROUP_NAMES, key=lambda k: group_ms[k])
     dom_name = GROUP_NAMES[dom]
-    dom_ms = group_ms[dom] / args.steps
+    dom_ms = group_ms[dom] / nprobe
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
@@ -138,7 +167,8 @@ def main():
                      "avg_launch_ms": round(dom_ms, 4), "bytes_per_launch": int(launch_bytes)},
         "path": {"bytes_per_frame": PATH_BYTES_PER_FRAME if not args.no_labels else 2 * P,
                  "frac_of_hbm_peak_per_gpu": round(fps / world * (PATH_BYTES_PER_FRAME if not args.no_labels else 2 * P) / (HBM_PEAK_GBS * 1e9), 4),
-                 "group_ms_per_step": {GROUP_NAMES[k]: round(group_ms[k] / args.steps, 3) for k in GROUP_NAMES}},
+                 "contexts": ns,
+                 "group_ms_per_step_single_context": {GROUP_NAMES[k]: round(group_ms[k] / nprobe, 3) for k in GROUP_NAMES}},
     }
 
     if rank == 0 and world == 1 and args.cpu_frames >= 12:
@@ -155,7 +185,8 @@ def main():
                                          f"single thread, no PNG/CSV writes, host has {os.cpu_count()} logical CPUs"}
     if rank == 0:
         print(json.dumps(out))
-    seg.close()
+    for sg in segs:
+        sg.close()
     if world > 1:
         dist.destroy_process_group()
 

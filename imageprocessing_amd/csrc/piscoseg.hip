@@ -49,7 +49,7 @@ struct pseg_ctx {
     DevBuf bits, partials, fsums, valid_dev, maskcnt, rowspans;
     // sparse workspaces
     DevBuf rowcnt, rowoff, framebase, ftot;      // ftot: per-frame totals {next, nkept, nsaved} and bases
-    DevBuf run_x, run_fy, fg_parent, ext, bg_parent, bg_left, minx, maxx, miny, maxy, area2, extrank,
+    DevBuf run_x, run_fy, fg_parent, ext, bg_parent, bg_left, minx, maxx, maxy, area2, extrank,
         keptrank, savedrank, objlabel, objflag;
     DevBuf rows, saved_row, saved_geo, crop_off, bits_off, maskbits, sums, crops_raw, crops_masked, crops_mask, totals;
     bool have_bits = false;       // threshold plane + masked sums already produced by the bg kernel
@@ -435,14 +435,77 @@ __global__ void k_synth(uint8_t *out, int H, int W, int frame0, unsigned long lo
 // sparse kernels: wrappers around pseg_core.h bodies
 // ------------------------------------------------------------------------------------------------
 #define GTID ((size_t)blockIdx.x * blockDim.x + threadIdx.x)
-__global__ void k_count_runs(SegState S, size_t n) { size_t g = GTID; if (g < n) count_runs_body(S, g); }
-__global__ void k_fill_runs(SegState S, size_t n) { size_t g = GTID; if (g < n) fill_runs_body(S, g); }
-__global__ void k_init_runs(SegState S, int nfg, int nbg)
+// inclusive prefix sum over the wave (DPP); lane 63 holds the total
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) { return wave_sum63(v); }
+__device__ __forceinline__ uint32_t lane_shr1(uint32_t v)      // value of lane-1, 0 for lane 0 (wave_shr:1)
 {
-    size_t g = GTID;
-    if (g < (size_t)nfg) init_run_body(S, (int)g);
-    if (g < (size_t)nbg) init_bg_body(S, (int)g);
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false);
 }
+// Foreground runs, one wave per group of RUNS_RPW rows (lane = 64-bit word of the current row; rows longer
+// than 64 words loop with a carry).  FILL = false: rowcnt[row] = number of runs.  FILL = true: write
+// run_x / run_fy from the row's first index; rows without runs are skipped without touching the plane.
+#define RUNS_RPW 16
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_runs(SegState S, int nrows)
+{
+    const int lane = threadIdx.x & 63;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RUNS_RPW;
+    if (row0 >= nrows) return;
+    unsigned long long todo;
+    {
+        const int row = row0 + lane;
+        bool want = lane < RUNS_RPW && row < nrows;
+        if (want) {
+            const int f = row / S.H;
+            if (!S.valid[f]) { want = false; if (!FILL) S.rowcnt[row] = 0; }
+            else if (FILL) want = seg_rowcount(S, f, row - f * S.H) != 0;
+        }
+        todo = __ballot(want);
+    }
+    while (todo) {
+        const int row = row0 + (__ffsll(todo) - 1);
+        todo &= todo - 1;
+        const int f = row / S.H, y = row - f * S.H;
+        const uint64_t *rb = S.bits + (size_t)row * S.WW;
+        uint32_t total = 0, carry = 0;
+        const int base = FILL ? seg_rowstart(S, f, y) : 0;
+        for (int w0 = 0; w0 < S.WW; w0 += 64) {
+            const int w = w0 + lane;
+            const uint64_t v = w < S.WW ? rb[w] : 0;
+            uint32_t top = (uint32_t)(v >> 63);
+            uint32_t prevtop = lane_shr1(top);
+            if (lane == 0) prevtop = carry;
+            uint64_t st = v & ~((v << 1) | prevtop);
+            uint32_t c = (uint32_t)__popcll(st);
+            uint32_t incl = wave_scan_incl(c);
+            if (FILL) {
+                int idx = base + (int)total + (int)(incl - c);
+                while (st) {
+                    int s = __ffsll((unsigned long long)st) - 1;
+                    st &= st - 1;
+                    uint64_t t = ~(v >> s);                       // zeros mark the run's extent from bit s
+                    int ones = t ? __ffsll((unsigned long long)t) - 1 : 64;
+                    int xe = 64 * w + s + ones - 1;
+                    if (s + ones == 64) {                           // run continues into the next words
+                        for (int k = w + 1; k < S.WW; k++) {
+                            uint64_t u = rb[k];
+                            if (u == ~0ull) { xe += 64; continue; }
+                            xe += __ffsll((unsigned long long)~u) - 1;
+                            break;
+                        }
+                    }
+                    S.run_x[idx] = (uint32_t)(64 * w + s) | ((uint32_t)xe << 16);
+                    S.run_fy[idx] = (uint32_t)y | ((uint32_t)f << 16);
+                    idx++;
+                }
+            }
+            total += __builtin_amdgcn_readlane(incl, 63);
+            carry = __builtin_amdgcn_readlane(top, 63);
+        }
+        if (!FILL && lane == 0) S.rowcnt[row] = total;
+    }
+}
+__global__ void k_init(SegState S, int nfg, int nt) { size_t g = GTID; if (g < (size_t)nt) init_body(S, (int)g, nfg); }
 __global__ void k_fg_union(SegState S, int nfg) { size_t g = GTID; if (g < (size_t)nfg) fg_union_body(S, (int)g); }
 __global__ void k_bg_union(SegState S, int nfg, int nt) { size_t g = GTID; if (g < (size_t)nt) bg_union_body(S, (int)g, nfg); }
 __global__ void k_flatten(SegState S, int nfg, int nbg)
@@ -452,7 +515,30 @@ __global__ void k_flatten(SegState S, int nfg, int nbg)
     if (g < (size_t)nbg) flatten_body(S.bg_parent, (int)g);
 }
 __global__ void k_resolve_ext(SegState S, int nfg) { size_t g = GTID; if (g < (size_t)nfg) resolve_ext_body(S, (int)g); }
-__global__ void k_bbox(SegState S, int nfg) { size_t g = GTID; if (g < (size_t)nfg) bbox_body(S, (int)g); }
+// bounding boxes: the 256 runs of a block are combined per object in an LDS hash table first, so that
+// only one set of global atomics is issued per (block, object)
+__global__ __launch_bounds__(256) void k_bbox(SegState S, int nfg)
+{
+    __shared__ int keys[512], vminx[512], vmaxx[512], vmaxy[512];
+    for (int i = threadIdx.x; i < 512; i += 256) { keys[i] = -1; vminx[i] = 0x7fffffff; vmaxx[i] = -1; vmaxy[i] = -1; }
+    __syncthreads();
+    size_t g = GTID;
+    if (g < (size_t)nfg) {
+        int r = (int)g, E = S.ext[r];
+        unsigned h = ((unsigned)E * 2654435761u) >> 23;       // 9 bits
+        for (;;) {
+            int old = atomicCAS(&keys[h], -1, E);
+            if (old == -1 || old == E) break;
+            h = (h + 1) & 511;
+        }
+        atomicMin(&vminx[h], run_xs(S, r));
+        atomicMax(&vmaxx[h], run_xe(S, r));
+        atomicMax(&vmaxy[h], (int)(S.run_fy[r] & 0xffffu));
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 512; i += 256)
+        if (keys[i] >= 0) bbox_flush(S, keys[i], vminx[i], vmaxx[i], vmaxy[i]);
+}
 __global__ void k_area(SegState S, int nfy) { size_t g = GTID; if (g < (size_t)nfy) area_body(S, (int)g); }
 
 // exclusive scan of rowcnt inside each frame (block per frame); ftot[f] = runs in frame f
@@ -483,14 +569,31 @@ __global__ __launch_bounds__(256) void k_scan_rows(SegState S, uint32_t *ftot)
     if (threadIdx.x == 0) { S.rowoff[(size_t)f * (H + 1) + H] = carry; ftot[f] = carry; }
 }
 
-// exclusive scan over <= a few thousand frames by one block: out[0..F], k interleaved columns
-__global__ void k_scan_small(const uint32_t *in, uint32_t *out, int F, int stride_in, int stride_out)
+// exclusive scan over the frames by one block: out[0..F] (strided input / output)
+__global__ __launch_bounds__(256) void k_scan_small(const uint32_t *in, uint32_t *out, int F, int stride_in, int stride_out)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        uint32_t acc = 0;
-        for (int f = 0; f < F; f++) { out[(size_t)f * stride_out] = acc; acc += in[(size_t)f * stride_in]; }
-        out[(size_t)F * stride_out] = acc;
+    __shared__ uint32_t sh[256];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < F; base += 256) {
+        int f = base + threadIdx.x;
+        uint32_t v = f < F ? in[(size_t)f * stride_in] : 0;
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 1; o < 256; o <<= 1) {
+            uint32_t t = threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
+            __syncthreads();
+            sh[threadIdx.x] += t;
+            __syncthreads();
+        }
+        uint32_t c0 = carry;
+        if (f < F) out[(size_t)f * stride_out] = c0 + sh[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 255) carry = c0 + sh[255];
+        __syncthreads();
     }
+    if (threadIdx.x == 0) out[(size_t)F * stride_out] = carry;
 }
 
 // ranks of external roots / kept / saved objects inside each frame (block per frame).
@@ -554,8 +657,9 @@ __global__ void k_emit(SegState S, int nfg, double min_seg, double min_save, con
     int c = nkept - 1 - S.keptrank[r];
     int i = (int)rowbase[f] + c;
     R.frame[i] = f; R.c[i] = c; R.label[i] = label; R.area2[i] = S.area2[r];
-    R.x[i] = S.minx[r]; R.y[i] = S.miny[r];
-    R.w[i] = S.maxx[r] - S.minx[r] + 1; R.h[i] = S.maxy[r] - S.miny[r] + 1;
+    const int y0 = (int)(S.run_fy[r] & 0xffffu);           // the root run lies in the object's first row
+    R.x[i] = S.minx[r]; R.y[i] = y0;
+    R.w[i] = S.maxx[r] - S.minx[r] + 1; R.h[i] = S.maxy[r] - y0 + 1;
     R.saved[i] = saved; R.root[i] = r;
     objflag[r] = 1 | (saved ? 2 : 0);
     if (saved) saved_row[(int)savedbase[f] + (nsaved - 1 - S.savedrank[r])] = i;
@@ -595,7 +699,12 @@ __global__ __launch_bounds__(256) void k_label_fill(SegState S, const int32_t *_
 // geometry of saved object s: geo[s*8] = f, x, y, w, h, root, words-per-row, row ; sz[s*3] = crop bytes,
 // mask words, row bands (a band = a run of rows of about CROP_BAND pixels: the unit of work of k_crops_sums)
 #define CROP_BAND 4096
-__host__ __device__ inline int crop_rows_per_band(int w) { int r = CROP_BAND / w; return r < 1 ? 1 : r; }
+__host__ __device__ inline int crop_rows_per_band(int w)
+{
+    int r = CROP_BAND / w, wpr = (w + 31) >> 5;
+    if (r * wpr > 4096) r = 4096 / wpr;                   // the band's mask words must fit the LDS buffer of k_crops_sums
+    return r < 1 ? 1 : r;
+}
 __global__ void k_saved_geo(const uint32_t *n_saved_p, const int32_t *saved_row, RowsDev R, int32_t *geo, unsigned long long *sz)
 {
     size_t g = GTID;
@@ -641,51 +750,44 @@ __global__ __launch_bounds__(1024) void k_scan_sizes(const unsigned long long *s
     if (threadIdx.x < 3) { outp[threadIdx.x][n] = (long long)carry[threadIdx.x]; totals[threadIdx.x] = (long long)carry[threadIdx.x]; }
 }
 
-// cumulative filled mask window of saved object s as bits (block per object, thread per 32-px word).
-// A pixel is set iff it belongs to the hole-filled region of a SAVED object iterated at or before
-// this one (root index >= own root): detection.py:206,245-246 (the shared mask accumulates).
-__global__ __launch_bounds__(256) void k_build_masks(SegState S, const int32_t *geo, const long long *bits_off,
-                                                     const int32_t *objflag, uint32_t *maskbits)
-{
-    int s = blockIdx.x;
-    const int32_t *o = geo + 8 * (size_t)s;
-    int f = o[0], bx = o[1], by = o[2], w = o[3], h = o[4], root = o[5], wpr = o[6];
-    uint32_t *mb = maskbits + bits_off[s];
-    for (int wi = threadIdx.x; wi < wpr * h; wi += blockDim.x) {
-        int yy = wi / wpr, wx = wi - yy * wpr;
-        int x0 = bx + 32 * wx, x1 = x0 + 31;
-        if (x1 > bx + w - 1) x1 = bx + w - 1;
-        int y = by + yy;
-        uint32_t bitsv = mask_word_body(S, objflag, f, y, x0, x1, root);
-        mb[wi] = bitsv;
-    }
-}
-
 __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
     return v;
 }
 
-// three crops + integer sums of one row band of a saved object (block per band; bands of ~4096 px keep
-// every block short, large objects are spread over many CUs).  Sums are combined with integer atomics
-// (exact, order-independent).
+// Three crops + integer sums of one row band of a saved object (block per band; bands of ~4096 px keep
+// every block short, large objects are spread over many CUs).
+//  phase 1: the band's cumulative filled mask as bits in LDS, one thread per 32-pixel word: a pixel is set iff
+//           it lies in the hole-filled region of a SAVED object iterated at or before this one (root index >=
+//           own root) -- detection.py:206,245-246, the frame mask accumulates over the object loop;
+//  phase 2: crops (detection.py:243-247) and the sums, combined across bands with integer atomics (exact).
 // sums[s*PSEG_NSUMS + k]: 0 N, 1 sum r, 2 sum c, 3 sum r^2, 4 sum c^2, 5 sum r*c, 6 min I, 7 max I, 8 sum I,
 //   9 filled area, 10..12 perimeter code counts (weight 1, sqrt2, (1+sqrt2)/2), 13 euler, 14 convex area
-__global__ __launch_bounds__(256) void k_crops_sums(SegState S, int n_saved, const int32_t *geo, const long long *crop_off,
-                                                    const long long *bits_off, const long long *band_off,
-                                                    const uint32_t *maskbits, const uint8_t *cleaned, const uint8_t *raw,
-                                                    uint8_t *c_raw, uint8_t *c_masked, uint8_t *c_mask, long long *sums)
+#define CROP_LDS_WORDS 4096
+__global__ __launch_bounds__(256) void k_crops_sums(SegState S, int n_saved, const int32_t *__restrict__ geo,
+                                                    const long long *__restrict__ crop_off, const long long *__restrict__ band_off,
+                                                    const int32_t *__restrict__ objflag, const uint8_t *__restrict__ cleaned,
+                                                    const uint8_t *__restrict__ raw, uint8_t *__restrict__ c_raw,
+                                                    uint8_t *__restrict__ c_masked, uint8_t *__restrict__ c_mask, long long *sums)
 {
+    __shared__ uint32_t mb[CROP_LDS_WORDS];
     int lo = 0, hi = n_saved;                             // object s with band_off[s] <= blockIdx.x < band_off[s+1]
     const long long bid = blockIdx.x;
     while (hi - lo > 1) { int m = (lo + hi) >> 1; if (band_off[m] <= bid) lo = m; else hi = m; }
     const int s = lo;
     const int32_t *o = geo + 8 * (size_t)s;
-    const int f = o[0], bx = o[1], by = o[2], w = o[3], h = o[4], wpr = o[6];
+    const int f = o[0], bx = o[1], by = o[2], w = o[3], h = o[4], root = o[5], wpr = o[6];
     const int rpb = crop_rows_per_band(w);
     const int r0 = (int)(bid - band_off[s]) * rpb, r1 = (r0 + rpb < h) ? r0 + rpb : h;
-    const uint32_t *mb = maskbits + bits_off[s];
+    const int nwords = (r1 - r0) * wpr;                   // <= CROP_LDS_WORDS by construction of the bands
+    for (int wi = threadIdx.x; wi < nwords; wi += 256) {
+        int yy = wi / wpr, wx = wi - yy * wpr;
+        int x0 = bx + 32 * wx, x1 = x0 + 31;
+        if (x1 > bx + w - 1) x1 = bx + w - 1;
+        mb[wi] = mask_word_body(S, objflag, f, by + r0 + yy, x0, x1, root);
+    }
+    __syncthreads();
     const size_t P = (size_t)S.H * S.W;
     const uint8_t *cl = cleaned + (size_t)f * P, *rw = raw + (size_t)f * P;
     const long long off = crop_off[s];
@@ -693,12 +795,13 @@ __global__ __launch_bounds__(256) void k_crops_sums(SegState S, int n_saved, con
     uint32_t imin = 255, imax = 0;
     const int np = (r1 - r0) * w;
     const float rcp = 1.0f / (float)w;
+#pragma unroll 4
     for (int p = threadIdx.x; p < np; p += 256) {
-        int yy = (int)((float)p * rcp);                   // p / w, corrected below (p < 2^24)
-        int xx = p - yy * w;
-        if (xx < 0) { yy--; xx += w; } else if (xx >= w) { yy++; xx -= w; }
-        yy += r0;
-        uint32_t bit = (mb[yy * wpr + (xx >> 5)] >> (xx & 31)) & 1u;
+        int yl = (int)((float)p * rcp);                   // p / w, corrected below (p < 2^24)
+        int xx = p - yl * w;
+        if (xx < 0) { yl--; xx += w; } else if (xx >= w) { yl++; xx -= w; }
+        const int yy = yl + r0;
+        uint32_t bit = (mb[yl * wpr + (xx >> 5)] >> (xx & 31)) & 1u;
         size_t gi = (size_t)(by + yy) * S.W + bx + xx;
         long long q = off + (long long)yy * w + xx;
         uint8_t cv = cl[gi];
@@ -764,7 +867,7 @@ extern "C" int pseg_destroy(pseg_ctx *ctx)
     hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->bits, &ctx->partials, &ctx->fsums, &ctx->valid_dev, &ctx->maskcnt, &ctx->rowspans, &ctx->rowcnt,
                       &ctx->rowoff, &ctx->framebase, &ctx->ftot, &ctx->run_x, &ctx->run_fy, &ctx->fg_parent, &ctx->ext,
-                      &ctx->bg_parent, &ctx->bg_left, &ctx->minx, &ctx->maxx, &ctx->miny, &ctx->maxy, &ctx->area2,
+                      &ctx->bg_parent, &ctx->bg_left, &ctx->minx, &ctx->maxx, &ctx->maxy, &ctx->area2,
                       &ctx->extrank, &ctx->keptrank, &ctx->savedrank, &ctx->objlabel, &ctx->objflag, &ctx->rows,
                       &ctx->saved_row, &ctx->saved_geo, &ctx->crop_off, &ctx->bits_off, &ctx->maskbits, &ctx->sums,
                       &ctx->crops_raw, &ctx->crops_masked, &ctx->crops_mask, &ctx->totals, &ctx->bounds, &ctx->band_off, &ctx->trash};
@@ -906,11 +1009,9 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
         HIPCHK(hipMemsetAsync(ctx->maskcnt.p, 0, 8, st));
         hipLaunchKernelGGL(k_mask_count, dim3(256), dim3(256), 0, st, mask, P, (unsigned long long *)ctx->maskcnt.p);
     }
-    HIPCHK(hipMemsetAsync(S.rowcnt, 0, (size_t)n * H * 4, st));
-    size_t nwords = (size_t)n * H * WW;
-    hipLaunchKernelGGL(k_count_runs, dim3(nblocks(nwords)), dim3(256), 0, st, S, nwords);
+    hipLaunchKernelGGL(k_runs<false>, dim3(nblocks((size_t)n * H, 4 * RUNS_RPW)), dim3(256), 0, st, S, n * H);
     hipLaunchKernelGGL(k_scan_rows, dim3(n), dim3(256), 0, st, S, ftot);
-    hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(64), 0, st, (const uint32_t *)ftot, S.framebase, n, 1, 1);
+    hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(256), 0, st, (const uint32_t *)ftot, S.framebase, n, 1, 1);
     HIPCHK(hipGetLastError());
     uint32_t nfg_u = 0;
     HIPCHK(hipMemcpyAsync(&nfg_u, S.framebase + n, 4, hipMemcpyDeviceToHost, st));
@@ -920,22 +1021,20 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
     const size_t cap = (size_t)(nfg > 0 ? nfg : 1);
     ENSURE(ctx->run_x, cap * 4); ENSURE(ctx->run_fy, cap * 4); ENSURE(ctx->fg_parent, cap * 4); ENSURE(ctx->ext, cap * 4);
     ENSURE(ctx->bg_parent, (size_t)nbg * 4); ENSURE(ctx->bg_left, (size_t)nbg * 4);
-    ENSURE(ctx->minx, cap * 4); ENSURE(ctx->maxx, cap * 4); ENSURE(ctx->miny, cap * 4); ENSURE(ctx->maxy, cap * 4);
+    ENSURE(ctx->minx, cap * 4); ENSURE(ctx->maxx, cap * 4); ENSURE(ctx->maxy, cap * 4);
     ENSURE(ctx->area2, cap * 4); ENSURE(ctx->extrank, cap * 4); ENSURE(ctx->keptrank, cap * 4); ENSURE(ctx->savedrank, cap * 4);
     ENSURE(ctx->objlabel, cap * 4); ENSURE(ctx->objflag, cap * 4);
     S.run_x = (uint32_t *)ctx->run_x.p; S.run_fy = (uint32_t *)ctx->run_fy.p;
     S.fg_parent = (int32_t *)ctx->fg_parent.p; S.ext = (int32_t *)ctx->ext.p;
     S.bg_parent = (int32_t *)ctx->bg_parent.p; S.bg_left = (int32_t *)ctx->bg_left.p;
-    S.minx = (int32_t *)ctx->minx.p; S.maxx = (int32_t *)ctx->maxx.p; S.miny = (int32_t *)ctx->miny.p; S.maxy = (int32_t *)ctx->maxy.p;
+    S.minx = (int32_t *)ctx->minx.p; S.maxx = (int32_t *)ctx->maxx.p; S.maxy = (int32_t *)ctx->maxy.p;
     S.area2 = (int32_t *)ctx->area2.p;
     S.extrank = (int32_t *)ctx->extrank.p; S.keptrank = (int32_t *)ctx->keptrank.p; S.savedrank = (int32_t *)ctx->savedrank.p;
     int32_t *objlabel = (int32_t *)ctx->objlabel.p, *objflag = (int32_t *)ctx->objflag.p;
 
-    hipLaunchKernelGGL(k_init_runs, dim3(nblocks(nbg)), dim3(256), 0, st, S, nfg, nbg);
-    if (nfg > 0) {
-        hipLaunchKernelGGL(k_fill_runs, dim3(nblocks(nwords)), dim3(256), 0, st, S, nwords);
-        hipLaunchKernelGGL(k_fg_union, dim3(nblocks(nfg)), dim3(256), 0, st, S, nfg);
-    }
+    if (nfg > 0) hipLaunchKernelGGL(k_runs<true>, dim3(nblocks((size_t)n * H, 4 * RUNS_RPW)), dim3(256), 0, st, S, n * H);
+    hipLaunchKernelGGL(k_init, dim3(nblocks(nbg)), dim3(256), 0, st, S, nfg, nbg);
+    if (nfg > 0) hipLaunchKernelGGL(k_fg_union, dim3(nblocks(nfg)), dim3(256), 0, st, S, nfg);
     hipLaunchKernelGGL(k_bg_union, dim3(nblocks(nbg)), dim3(256), 0, st, S, nfg, nbg);
     hipLaunchKernelGGL(k_flatten, dim3(nblocks(nbg)), dim3(256), 0, st, S, nfg, nbg);
     if (nfg > 0) {
@@ -944,8 +1043,8 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
         hipLaunchKernelGGL(k_area, dim3(nblocks((size_t)n * H)), dim3(256), 0, st, S, n * H);
     }
     hipLaunchKernelGGL(k_rank, dim3(n), dim3(256), 0, st, S, min_seg, min_save, ftot3);
-    hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(64), 0, st, (const uint32_t *)(ftot3 + 1), rowbase, n, 3, 1);
-    hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(64), 0, st, (const uint32_t *)(ftot3 + 2), savedbase, n, 3, 1);
+    hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(256), 0, st, (const uint32_t *)(ftot3 + 1), rowbase, n, 3, 1);
+    hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(256), 0, st, (const uint32_t *)(ftot3 + 2), savedbase, n, 3, 1);
     HIPCHK(hipGetLastError());
     // rows: one per kept object; n_rows <= external roots <= nfg bounds the buffers without a host round trip
     const size_t rcap = cap, scap = cap;
@@ -997,15 +1096,12 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
     if (n_saved > 0) {
         if (h_tot[2] > 0x7fffffffLL) return fail(ctx, PSEG_ERR_CAPACITY, "too many crop bands");
         ENSURE(ctx->crops_raw, (size_t)h_tot[0]); ENSURE(ctx->crops_masked, (size_t)h_tot[0]); ENSURE(ctx->crops_mask, (size_t)h_tot[0]);
-        ENSURE(ctx->maskbits, (size_t)h_tot[1] * 4);
         ENSURE(ctx->sums, (size_t)n_saved * PSEG_NSUMS * 8);
         hipLaunchKernelGGL(k_init_sums, dim3(nblocks((size_t)n_saved * PSEG_NSUMS)), dim3(256), 0, st, (long long *)ctx->sums.p, n_saved);
-        hipLaunchKernelGGL(k_build_masks, dim3(n_saved), dim3(256), 0, st, S, (const int32_t *)geo, (const long long *)ctx->bits_off.p,
-                           (const int32_t *)objflag, (uint32_t *)ctx->maskbits.p);
         hipLaunchKernelGGL(k_crops_sums, dim3((unsigned)h_tot[2]), dim3(256), 0, st, S, n_saved, (const int32_t *)geo,
-                           (const long long *)ctx->crop_off.p, (const long long *)ctx->bits_off.p, (const long long *)ctx->band_off.p,
-                           (const uint32_t *)ctx->maskbits.p, cleaned, raw, (uint8_t *)ctx->crops_raw.p,
-                           (uint8_t *)ctx->crops_masked.p, (uint8_t *)ctx->crops_mask.p, (long long *)ctx->sums.p);
+                           (const long long *)ctx->crop_off.p, (const long long *)ctx->band_off.p, (const int32_t *)objflag,
+                           cleaned, raw, (uint8_t *)ctx->crops_raw.p, (uint8_t *)ctx->crops_masked.p,
+                           (uint8_t *)ctx->crops_mask.p, (long long *)ctx->sums.p);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(ctx->ev[5], st));

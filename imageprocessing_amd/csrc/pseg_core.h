@@ -57,7 +57,7 @@ struct SegState {
     int32_t *bg_parent;
     int32_t *bg_left;                // foreground run immediately left of the gap, -1 for j = 0
     // per object, indexed by its root run
-    int32_t *minx, *maxx, *miny, *maxy;
+    int32_t *minx, *maxx, *maxy;        // (min y = row of the root run)
     int32_t *area2;                  // 2*Q4 + Q3 = 2 * contourArea
     int32_t *extrank, *keptrank, *savedrank;   // exclusive ranks inside the frame
 };
@@ -69,64 +69,8 @@ PSEG_HD int seg_b0(const SegState &S, int f) { return (int)S.framebase[f] + f * 
 PSEG_HD int run_xs(const SegState &S, int r) { return (int)(S.run_x[r] & 0xffffu); }
 PSEG_HD int run_xe(const SegState &S, int r) { return (int)(S.run_x[r] >> 16); }
 
-PSEG_HD uint64_t seg_starts(const SegState &S, size_t g, int w, uint64_t v)
-{
-    uint64_t prev = w > 0 ? (S.bits[g - 1] >> 63) : 0;
-    return v & ~((v << 1) | prev);
-}
-
-// ---- 1. count foreground runs per row (thread per 64-bit word) -------------------------------
-PSEG_HD void count_runs_body(const SegState &S, size_t g)
-{
-    int w = (int)(g % S.WW);
-    size_t fy = g / S.WW;
-    int f = (int)(fy / S.H);
-    if (!S.valid[f]) return;
-    uint64_t v = S.bits[g];
-    if (!v) return;
-    uint64_t st = seg_starts(S, g, w, v);
-    if (st) PSEG_ATOMIC_ADD(&S.rowcnt[fy], (uint32_t)PSEG_POPC64(st));
-}
-
-// ---- 2. write the runs (thread per word) ------------------------------------------------------
-PSEG_HD void fill_runs_body(const SegState &S, size_t g)
-{
-    int w = (int)(g % S.WW);
-    size_t fy = g / S.WW;
-    int f = (int)(fy / S.H), y = (int)(fy % S.H);
-    if (!S.valid[f]) return;
-    uint64_t v = S.bits[g];
-    if (!v) return;
-    uint64_t st = seg_starts(S, g, w, v);
-    if (!st) return;
-    int idx = seg_rowstart(S, f, y);
-    size_t g0 = g - w;
-    uint64_t carry = 0;                                   // top bit of the previous word
-    for (int k = 0; k < w; k++) {                         // independent loads: the compiler can batch them
-        uint64_t u = S.bits[g0 + k];
-        idx += PSEG_POPC64(u & ~((u << 1) | carry));
-        carry = u >> 63;
-    }
-    while (st) {
-        int s = PSEG_CTZ64(st);
-        st &= st - 1;
-        uint64_t t = ~(v >> s);                       // zeros mark the run's extent from bit s
-        int ones = t ? PSEG_CTZ64(t) : 64;
-        if (ones > 64 - s) ones = 64 - s;
-        int xe = 64 * w + s + ones - 1;
-        if (s + ones == 64) {                           // run continues into the next words
-            for (int k = w + 1; k < S.WW; k++) {
-                uint64_t u = S.bits[g0 + k];
-                if (u == ~0ull) { xe += 64; continue; }
-                xe += (~u) ? PSEG_CTZ64(~u) : 0;
-                break;
-            }
-        }
-        S.run_x[idx] = (uint32_t)(64 * w + s) | ((uint32_t)xe << 16);
-        S.run_fy[idx] = (uint32_t)y | ((uint32_t)f << 16);
-        idx++;
-    }
-}
+// Runs are extracted by one wave per row (k_count_runs / k_fill_runs in piscoseg.hip): starts = v & ~((v << 1) | carry),
+// an in-wave prefix sum gives every word its first run index.
 
 // ---- union-find (link the larger root under the smaller one) -------------------------------
 PSEG_HD int uf_find(const int32_t *parent, int a)
@@ -135,11 +79,24 @@ PSEG_HD int uf_find(const int32_t *parent, int a)
     while (p != a) { a = p; p = parent[a]; }
     return a;
 }
+// find with path halving: every visited node is re-pointed to its grandparent.  The plain stores race
+// with other threads' atomicMin on roots only in a benign way: a node's parent is always replaced by
+// one of its current ancestors (values only decrease along a chain), never by a foreign index.
+PSEG_HD int uf_find_halve(int32_t *parent, int a)
+{
+    int p = parent[a];
+    while (p != a) {
+        int g = parent[p];
+        if (g != p) parent[a] = g;
+        a = p; p = g;
+    }
+    return a;
+}
 PSEG_HD void uf_union(int32_t *parent, int a, int b)
 {
     for (int guard = 0; guard < (1 << 30); guard++) {
-        a = uf_find(parent, a);
-        b = uf_find(parent, b);
+        a = uf_find_halve(parent, a);
+        b = uf_find_halve(parent, b);
         if (a == b) return;
         int hi = a > b ? a : b, lo = a > b ? b : a;
         int old = PSEG_ATOMIC_MIN(&parent[hi], lo);
@@ -148,13 +105,27 @@ PSEG_HD void uf_union(int32_t *parent, int a, int b)
     }
 }
 
-PSEG_HD void init_run_body(const SegState &S, int r)
+// thread t < nfg: run t and the gap left of it; thread t >= nfg: trailing gap of row t - nfg.
+// Gaps that touch the zero padding (first / last gap of a row, every gap of the first / last row) start
+// with the frame's smallest background index as parent: the frame-connected background needs no unions.
+PSEG_HD void init_body(const SegState &S, int t, int nfg)
 {
-    S.fg_parent[r] = r;
-    S.minx[r] = 0x7fffffff; S.miny[r] = 0x7fffffff; S.maxx[r] = -1; S.maxy[r] = -1;
-    S.area2[r] = 0;
+    if (t < nfg) {
+        int y = (int)(S.run_fy[t] & 0xffffu), f = (int)(S.run_fy[t] >> 16);
+        S.fg_parent[t] = t;
+        S.minx[t] = 0x7fffffff; S.maxx[t] = -1; S.maxy[t] = -1;
+        S.area2[t] = 0;
+        int j = t - seg_rowstart(S, f, y), b = t + f * S.H + y;
+        S.bg_parent[b] = (j == 0 || y == 0 || y == S.H - 1) ? seg_b0(S, f) : b;
+        S.bg_left[b] = j == 0 ? -1 : t - 1;
+    } else {
+        int fy = t - nfg, f = fy / S.H, y = fy % S.H;
+        int rs = seg_rowstart(S, f, y), n = seg_rowcount(S, f, y);
+        int b = rs + f * S.H + y + n;
+        S.bg_parent[b] = seg_b0(S, f);
+        S.bg_left[b] = n == 0 ? -1 : rs + n - 1;
+    }
 }
-PSEG_HD void init_bg_body(const SegState &S, int b) { S.bg_parent[b] = b; }
 
 // ---- 3. foreground unions, 8-connectivity (thread per run) -----------------------------------
 PSEG_HD void fg_union_body(const SegState &S, int r)
@@ -178,11 +149,7 @@ PSEG_HD void bg_union_elem(const SegState &S, int f, int y, int j)
     int bb = rs + f * S.H + y, b = bb + j;
     int a = j == 0 ? -1 : run_xe(S, rs + j - 1) + 1;
     int e = j == n ? S.W : run_xs(S, rs + j) - 1;
-    S.bg_left[b] = j == 0 ? -1 : rs + j - 1;
-    // gaps that touch the zero padding (first / last gap of a row, every gap of the first / last row)
-    // are linked straight to the frame's smallest background index: no chains through the rows
-    if (j == 0 || j == n || y == 0 || y == S.H - 1) uf_union(S.bg_parent, b, seg_b0(S, f));
-    if (y == 0) return;
+    if (y == 0) return;                                  // (padding-adjacent gaps were attached to B0 by init_body)
     int ps = seg_rowstart(S, f, y - 1), pn = rs - ps, pb = ps + f * S.H + (y - 1);
     // first gap j' of the previous row whose right end (xs_{j'} - 1, or W for j' = pn) >= a
     int lo = 0, hi = pn;
@@ -227,16 +194,13 @@ PSEG_HD int bg_gid(const SegState &S, int f, int b)
     return S.ext[S.bg_left[hb]];
 }
 
-// ---- 6. bounding boxes (thread per run) -------------------------------------------------------
-PSEG_HD void bbox_body(const SegState &S, int r)
+// ---- 6. bounding boxes: min x / max x / max y per external object (min y is the root's row).
+// k_bbox first combines the runs of a block in an LDS hash table, then calls this once per (block, object).
+PSEG_HD void bbox_flush(const SegState &S, int E, int xs, int xe, int y)
 {
-    int E = S.ext[r];
-    int y = (int)(S.run_fy[r] & 0xffffu);
-    int xs = run_xs(S, r), xe = run_xe(S, r);
     // monotone values: a (possibly stale) read that already satisfies the bound makes the atomic redundant
     if (xs < S.minx[E]) PSEG_ATOMIC_MIN(&S.minx[E], xs);
     if (xe > S.maxx[E]) PSEG_ATOMIC_MAX(&S.maxx[E], xe);
-    if (y < S.miny[E]) PSEG_ATOMIC_MIN(&S.miny[E], y);
     if (y > S.maxy[E]) PSEG_ATOMIC_MAX(&S.maxy[E], y);
 }
 

@@ -1,0 +1,112 @@
+"""Multi-GPU layout on CPU: the reference's batch partition, table packing / merging, and the
+gather collective with world_size 2 over gloo."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from imageprocessing_amd import sharding
+from oracle import pipeline_ref
+
+
+@pytest.mark.parametrize("n", [1, 11, 150, 199, 200, 201, 399, 400, 401, 650, 1000, 10000])
+def test_batches_match_reference_partition(n):
+    files = list(range(n))
+    want = pipeline_ref.batches_of(files)                      # restates segmenter.py:209-213
+    got = sharding.batches_of(n)
+    assert [(b[0], len(b)) for b in want] == got
+    assert sum(m for _, m in got) == n
+
+
+def test_assign_batches_contiguous_and_balanced():
+    b = sharding.batches_of(10000)
+    for world in (1, 2, 4, 8):
+        parts = sharding.assign_batches(b, world)
+        assert sum(parts, []) == b
+        sizes = [len(p) for p in parts]
+        assert max(sizes) - min(sizes) <= 1
+
+
+class _Tab:
+    pass
+
+
+def fake_table(n_frames, rng, crop_bytes_per_saved=50):
+    t = _Tab()
+    rows_per_frame = rng.integers(0, 6, n_frames)
+    nr = int(rows_per_frame.sum())
+    t.n_frames = n_frames
+    t.frame_row_offset = np.concatenate([[0], np.cumsum(rows_per_frame)]).astype(np.int32)
+    t.frame_n_contours = (rows_per_frame + 2).astype(np.int32)
+    t.frame_valid = np.ones(n_frames, np.uint8)
+    t.frame_mean = rng.random(n_frames)
+    t.frame_std = rng.random(n_frames)
+    t.frame = np.repeat(np.arange(n_frames), rows_per_frame).astype(np.int32)
+    t.c = np.concatenate([np.arange(k) for k in rows_per_frame] + [np.zeros(0, int)]).astype(np.int32)
+    t.label = t.c + 1
+    t.area = rng.random(nr) * 1000
+    t.x, t.y, t.w, t.h = (rng.integers(0, 100, nr).astype(np.int32) for _ in range(4))
+    t.saved = (t.area > 400).astype(np.uint8)
+    t.props = rng.random((nr, 32))
+    t.saved_row = np.nonzero(t.saved)[0].astype(np.int32)
+    ns = len(t.saved_row)
+    t.crop_offset = (np.arange(ns + 1) * crop_bytes_per_saved).astype(np.int64)
+    t.sums = rng.integers(0, 1000, (ns, 24)).astype(np.int64)
+    t.crop_bytes = ns * crop_bytes_per_saved
+    return t
+
+
+def test_pack_merge_is_independent_of_sharding():
+    rng = np.random.default_rng(0)
+    shards = [fake_table(7, rng), fake_table(5, rng), fake_table(9, rng)]
+    bases = [0, 7, 12]
+    blobs = [sharding.pack_table(t, b) for t, b in zip(shards, bases)]
+    merged = sharding.merge_tables([sharding.unpack_table(b) for b in reversed(blobs)])
+    assert list(merged["frame"]) == sum([list(t.frame + b) for t, b in zip(shards, bases)], [])
+    assert merged["frame_row_offset"][-1] == sum(len(t.frame) for t in shards)
+    assert len(merged["frame_row_offset"]) == 22
+    assert np.array_equal(merged["area"], np.concatenate([t.area for t in shards]))
+    for s, r in enumerate(merged["saved_row"]):
+        assert merged["saved"][r] == 1
+    assert merged["crop_offset"][-1] == sum(t.crop_bytes for t in shards)
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(rank)
+    tab = fake_table(4 + rank, rng)
+    blob = sharding.pack_table(tab, frame_base=100 * rank)
+    got = sharding.gather_tables(blob)
+    if rank == 0:
+        merged = sharding.merge_tables([sharding.unpack_table(b) for b in got])
+        q.put((len(got), int(merged["frame_row_offset"][-1]), [int(v) for v in merged["frame"][:3]]))
+    else:
+        assert got is None
+        q.put(len(tab.frame))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_tables_gloo_world2():
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    r0 = [r for r in res if isinstance(r, tuple)][0]
+    r1 = [r for r in res if not isinstance(r, tuple)][0]
+    rows0 = len(fake_table(4, np.random.default_rng(0)).frame)
+    assert r0[0] == 2 and r0[1] == rows0 + r1
