@@ -462,16 +462,25 @@ __global__ __launch_bounds__(256) void k_runs(SegState S, int nrows)
         }
         todo = __ballot(want);
     }
-    while (todo) {
-        const int row = row0 + (__ffsll(todo) - 1);
-        todo &= todo - 1;
+    // rows of up to 64 words: the words of all wanted rows are loaded first (one memory latency per wave)
+    uint64_t pre[RUNS_RPW];
+    const bool small = S.WW <= 64;
+    if (small) {
+#pragma unroll
+        for (int i = 0; i < RUNS_RPW; i++)
+            pre[i] = (((todo >> i) & 1ull) && lane < S.WW) ? S.bits[(size_t)(row0 + i) * S.WW + lane] : 0;
+    }
+#pragma unroll
+    for (int i = 0; i < RUNS_RPW; i++) {
+        if (!((todo >> i) & 1ull)) continue;
+        const int row = row0 + i;
         const int f = row / S.H, y = row - f * S.H;
         const uint64_t *rb = S.bits + (size_t)row * S.WW;
         uint32_t total = 0, carry = 0;
         const int base = FILL ? seg_rowstart(S, f, y) : 0;
         for (int w0 = 0; w0 < S.WW; w0 += 64) {
             const int w = w0 + lane;
-            const uint64_t v = w < S.WW ? rb[w] : 0;
+            const uint64_t v = small ? pre[i] : (w < S.WW ? rb[w] : 0);
             uint32_t top = (uint32_t)(v >> 63);
             uint32_t prevtop = lane_shr1(top);
             if (lane == 0) prevtop = carry;
@@ -790,29 +799,54 @@ __global__ __launch_bounds__(256) void k_crops_sums(SegState S, int n_saved, con
     __syncthreads();
     const size_t P = (size_t)S.H * S.W;
     const uint8_t *cl = cleaned + (size_t)f * P, *rw = raw + (size_t)f * P;
+    const bool same = (raw == cleaned);                   // fused path: the Crops/ plane is cut from the same image
     const long long off = crop_off[s];
     unsigned long long a[7] = {0, 0, 0, 0, 0, 0, 0};
     uint32_t imin = 255, imax = 0;
-    const int np = (r1 - r0) * w;
-    const float rcp = 1.0f / (float)w;
-#pragma unroll 4
-    for (int p = threadIdx.x; p < np; p += 256) {
-        int yl = (int)((float)p * rcp);                   // p / w, corrected below (p < 2^24)
-        int xx = p - yl * w;
-        if (xx < 0) { yl--; xx += w; } else if (xx >= w) { yl++; xx -= w; }
-        const int yy = yl + r0;
-        uint32_t bit = (mb[yl * wpr + (xx >> 5)] >> (xx & 31)) & 1u;
-        size_t gi = (size_t)(by + yy) * S.W + bx + xx;
-        long long q = off + (long long)yy * w + xx;
-        uint8_t cv = cl[gi];
-        c_raw[q] = rw[gi];
-        c_mask[q] = bit ? 255 : 0;
-        c_masked[q] = bit ? cv : 255;
-        if (bit) {
-            a[0] += 1; a[1] += yy; a[2] += xx;
-            a[3] += (unsigned long long)yy * yy; a[4] += (unsigned long long)xx * xx; a[5] += (unsigned long long)yy * xx;
-            a[6] += cv;
-            imin = cv < imin ? cv : imin; imax = cv > imax ? cv : imax;
+    // thread = 4 consecutive pixels of a row: one (unaligned) 32-bit load / store per plane instead of four byte ones
+    const int cpr = (w + 3) >> 2, nitem = (r1 - r0) * cpr;
+    const float rcp = 1.0f / (float)cpr;
+#pragma unroll 2
+    for (int p = threadIdx.x; p < nitem; p += 256) {
+        int yl = (int)((float)p * rcp);                   // p / cpr, corrected below (p < 2^24)
+        int c = p - yl * cpr;
+        if (c < 0) { yl--; c += cpr; } else if (c >= cpr) { yl++; c -= cpr; }
+        const int yy = yl + r0, xx = 4 * c;
+        const uint32_t bits4 = (mb[yl * wpr + (xx >> 5)] >> (xx & 31)) & 0xfu;
+        const uint8_t *src = cl + (size_t)(by + yy) * S.W + bx + xx;
+        const uint8_t *srw = rw + (size_t)(by + yy) * S.W + bx + xx;
+        const long long q = off + (long long)yy * w + xx;
+        uint32_t cv4, rv4;
+        const int nv = w - xx >= 4 ? 4 : w - xx;
+        if (nv == 4) {
+            __builtin_memcpy(&cv4, src, 4);
+            if (same) rv4 = cv4; else __builtin_memcpy(&rv4, srw, 4);
+            uint32_t m4 = (bits4 & 1u ? 0xffu : 0u) | (bits4 & 2u ? 0xff00u : 0u) | (bits4 & 4u ? 0xff0000u : 0u) | (bits4 & 8u ? 0xff000000u : 0u);
+            uint32_t cm4 = (cv4 & m4) | ~m4;                // where(mask, crop, 255)
+            __builtin_memcpy(c_raw + q, &rv4, 4);
+            __builtin_memcpy(c_mask + q, &m4, 4);
+            __builtin_memcpy(c_masked + q, &cm4, 4);
+        } else {
+            cv4 = 0;
+            for (int k = 0; k < nv; k++) {
+                uint8_t cv = src[k];
+                bool bit = (bits4 >> k) & 1u;
+                cv4 |= (uint32_t)cv << (8 * k);
+                c_raw[q + k] = same ? cv : srw[k];
+                c_mask[q + k] = bit ? 255 : 0;
+                c_masked[q + k] = bit ? cv : 255;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if ((bits4 >> k) & 1u) {                      // bits beyond the row end are zero by construction of the mask words
+                const uint32_t cv = (cv4 >> (8 * k)) & 255u;
+                const int x = xx + k;
+                a[0] += 1; a[1] += yy; a[2] += x;
+                a[3] += (unsigned long long)yy * yy; a[4] += (unsigned long long)x * x; a[5] += (unsigned long long)yy * x;
+                a[6] += cv;
+                imin = cv < imin ? cv : imin; imax = cv > imax ? cv : imax;
+            }
         }
     }
     for (int k = 0; k < 7; k++) a[k] = wave_sum_u64(a[k]);
