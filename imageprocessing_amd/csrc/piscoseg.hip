@@ -708,10 +708,11 @@ __global__ __launch_bounds__(256) void k_label_fill(SegState S, const int32_t *_
 // geometry of saved object s: geo[s*8] = f, x, y, w, h, root, words-per-row, row ; sz[s*3] = crop bytes,
 // mask words, row bands (a band = a run of rows of about CROP_BAND pixels: the unit of work of k_crops_sums)
 #define CROP_BAND 4096
+#define CROP_LDS_WORDS 1536          // mask words of a band + 2 halo rows on each side (frames up to 8192 px wide)
 __host__ __device__ inline int crop_rows_per_band(int w)
 {
-    int r = CROP_BAND / w, wpr = (w + 31) >> 5;
-    if (r * wpr > 4096) r = 4096 / wpr;                   // the band's mask words must fit the LDS buffer of k_crops_sums
+    int r = CROP_BAND / w;
+    if (r > 1020) r = 1020;
     return r < 1 ? 1 : r;
 }
 __global__ void k_saved_geo(const uint32_t *n_saved_p, const int32_t *saved_row, RowsDev R, int32_t *geo, unsigned long long *sz)
@@ -724,7 +725,7 @@ __global__ void k_saved_geo(const uint32_t *n_saved_p, const int32_t *saved_row,
     o[0] = R.frame[i]; o[1] = R.x[i]; o[2] = R.y[i]; o[3] = w; o[4] = h; o[5] = R.root[i]; o[6] = wpr; o[7] = i;
     int rpb = crop_rows_per_band(w);
     sz[3 * g] = (unsigned long long)w * h;
-    sz[3 * g + 1] = (unsigned long long)wpr * h;
+    sz[3 * g + 1] = (unsigned long long)h;                 // rows: offset of the object's per-row extremes
     sz[3 * g + 2] = (unsigned long long)((h + rpb - 1) / rpb);
 }
 // exclusive scans of the three size columns by one block of 1024 threads; out[k][0..n]
@@ -773,14 +774,15 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 //  phase 2: crops (detection.py:243-247) and the sums, combined across bands with integer atomics (exact).
 // sums[s*PSEG_NSUMS + k]: 0 N, 1 sum r, 2 sum c, 3 sum r^2, 4 sum c^2, 5 sum r*c, 6 min I, 7 max I, 8 sum I,
 //   9 filled area, 10..12 perimeter code counts (weight 1, sqrt2, (1+sqrt2)/2), 13 euler, 14 convex area
-#define CROP_LDS_WORDS 4096
 __global__ __launch_bounds__(256) void k_crops_sums(SegState S, int n_saved, const int32_t *__restrict__ geo,
                                                     const long long *__restrict__ crop_off, const long long *__restrict__ band_off,
                                                     const int32_t *__restrict__ objflag, const uint8_t *__restrict__ cleaned,
                                                     const uint8_t *__restrict__ raw, uint8_t *__restrict__ c_raw,
-                                                    uint8_t *__restrict__ c_masked, uint8_t *__restrict__ c_mask, long long *sums)
+                                                    uint8_t *__restrict__ c_masked, uint8_t *__restrict__ c_mask, long long *sums,
+                                                    const long long *__restrict__ row_off, int32_t *__restrict__ rowext)
 {
-    __shared__ uint32_t mb[CROP_LDS_WORDS];
+    __shared__ uint32_t mbuf[CROP_LDS_WORDS];             // mask bits of rows r0-2 .. r1+1 (zero outside the window)
+    __shared__ uint32_t bd[CROP_LDS_WORDS];               // 4-neighbour border bits of rows r0-1 .. r1
     int lo = 0, hi = n_saved;                             // object s with band_off[s] <= blockIdx.x < band_off[s+1]
     const long long bid = blockIdx.x;
     while (hi - lo > 1) { int m = (lo + hi) >> 1; if (band_off[m] <= bid) lo = m; else hi = m; }
@@ -789,14 +791,31 @@ __global__ __launch_bounds__(256) void k_crops_sums(SegState S, int n_saved, con
     const int f = o[0], bx = o[1], by = o[2], w = o[3], h = o[4], root = o[5], wpr = o[6];
     const int rpb = crop_rows_per_band(w);
     const int r0 = (int)(bid - band_off[s]) * rpb, r1 = (r0 + rpb < h) ? r0 + rpb : h;
-    const int nwords = (r1 - r0) * wpr;                   // <= CROP_LDS_WORDS by construction of the bands
-    for (int wi = threadIdx.x; wi < nwords; wi += 256) {
-        int yy = wi / wpr, wx = wi - yy * wpr;
-        int x0 = bx + 32 * wx, x1 = x0 + 31;
-        if (x1 > bx + w - 1) x1 = bx + w - 1;
-        mb[wi] = mask_word_body(S, objflag, f, by + r0 + yy, x0, x1, root);
+    const int nrows = r1 - r0;
+    for (int wi = threadIdx.x; wi < (nrows + 4) * wpr; wi += 256) {
+        int yl = wi / wpr, wx = wi - yl * wpr;
+        int yy = r0 - 2 + yl;
+        uint32_t v = 0;
+        if (yy >= 0 && yy < h) {
+            int x0 = bx + 32 * wx, x1 = x0 + 31;
+            if (x1 > bx + w - 1) x1 = bx + w - 1;
+            v = mask_word_body(S, objflag, f, by + yy, x0, x1, root);
+        }
+        mbuf[wi] = v;
     }
     __syncthreads();
+    // border = mask minus its erosion by the 4-neighbour cross, zero outside the window
+    // (skimage perimeter(image, 4): binary_erosion(..., border_value=0), _regionprops_utils.py:225-231)
+    for (int wi = threadIdx.x; wi < (nrows + 2) * wpr; wi += 256) {
+        int yl = wi / wpr, wx = wi - yl * wpr;             // row r0-1+yl  ->  mbuf row yl+1
+        const uint32_t *m = mbuf + (yl + 1) * wpr;
+        uint32_t c = m[wx], up = m[wx - wpr], dn = m[wx + wpr];
+        uint32_t lf = (c << 1) | (wx > 0 ? m[wx - 1] >> 31 : 0u);
+        uint32_t rt = (c >> 1) | (wx + 1 < wpr ? m[wx + 1] << 31 : 0u);
+        bd[wi] = c & ~(up & dn & lf & rt);
+    }
+    __syncthreads();
+    const uint32_t *mb = mbuf + 2 * wpr;                  // row r0 of the band
     const size_t P = (size_t)S.H * S.W;
     const uint8_t *cl = cleaned + (size_t)f * P, *rw = raw + (size_t)f * P;
     const bool same = (raw == cleaned);                   // fused path: the Crops/ plane is cut from the same image
@@ -849,17 +868,143 @@ __global__ __launch_bounds__(256) void k_crops_sums(SegState S, int n_saved, con
             }
         }
     }
+    // perimeter codes (skimage perimeter, _regionprops_utils.py:233-249): for a border pixel the 3x3 sum with
+    // weights [[10,2,10],[2,1,2],[10,2,10]] over the border image is 1 + 2*n4 + 10*nd
+    uint32_t pc1 = 0, pc2 = 0, pc3 = 0;
+    for (int wi = threadIdx.x; wi < nrows * wpr; wi += 256) {
+        int yl = wi / wpr, wx = wi - yl * wpr;
+        const uint32_t *bc = bd + (yl + 1) * wpr;          // border row r0+yl
+        uint32_t v = bc[wx];
+        while (v) {
+            int k = __ffs(v) - 1;
+            v &= v - 1;
+            int x = 32 * wx + k;
+            auto bit = [&](const uint32_t *row, int xx) -> int {
+                return (xx >= 0 && xx < 32 * wpr) ? (int)((row[xx >> 5] >> (xx & 31)) & 1u) : 0;
+            };
+            int n4 = bit(bc, x - 1) + bit(bc, x + 1) + bit(bc - wpr, x) + bit(bc + wpr, x);
+            int nd = bit(bc - wpr, x - 1) + bit(bc - wpr, x + 1) + bit(bc + wpr, x - 1) + bit(bc + wpr, x + 1);
+            if ((n4 == 2 || n4 == 3) && nd <= 2) pc1++;                       // codes 5,7,15,17,25,27 -> 1
+            else if ((n4 == 0 && nd == 2) || (n4 == 1 && nd == 3)) pc2++;      // codes 21,33 -> sqrt(2)
+            else if (n4 == 1 && (nd == 1 || nd == 2)) pc3++;                   // codes 13,23 -> (1+sqrt(2))/2
+        }
+    }
+    // Euler number, 8-connectivity (skimage euler_number, _regionprops_utils.py:140-181): 2x2 quads of the
+    // zero-padded window; code 8 = only top-left set, 6 = top-right + bottom-left, 14 = all but bottom-right
+    int eul = 0;
+    {
+        const int ylast = (r1 == h) ? nrows + 1 : nrows;   // the last band also owns the quads below the window
+        for (int wi = threadIdx.x; wi < ylast * (wpr + 1); wi += 256) {
+            int yl = wi / (wpr + 1), wx = wi - yl * (wpr + 1);
+            const uint32_t *B = mbuf + (yl + 2) * wpr, *T = B - wpr;     // bottom row r0+yl, top row r0+yl-1
+            uint32_t tr = wx < wpr ? T[wx] : 0u, br = wx < wpr ? B[wx] : 0u;
+            uint32_t tl = (tr << 1) | (wx > 0 ? T[wx - 1] >> 31 : 0u), bl = (br << 1) | (wx > 0 ? B[wx - 1] >> 31 : 0u);
+            eul += __popc(tl & ~tr & ~bl & ~br) - __popc(~tl & tr & bl & ~br) - __popc(tl & tr & bl & ~br);
+        }
+    }
+    // first / last set column of every row of the band (input of the convex hull kernel)
+    for (int yl = threadIdx.x; yl < nrows; yl += 256) {
+        const uint32_t *m = mb + yl * wpr;
+        int first = 0x7fffffff, last = -1;
+        for (int wx = 0; wx < wpr; wx++) if (m[wx]) { first = 32 * wx + __ffs(m[wx]) - 1; break; }
+        for (int wx = wpr - 1; wx >= 0; wx--) if (m[wx]) { last = 32 * wx + 31 - __clz(m[wx]); break; }
+        rowext[2 * (row_off[s] + r0 + yl)] = first;
+        rowext[2 * (row_off[s] + r0 + yl) + 1] = last;
+    }
     for (int k = 0; k < 7; k++) a[k] = wave_sum_u64(a[k]);
     for (int o2 = 32; o2 > 0; o2 >>= 1) {
         uint32_t t0 = __shfl_down(imin, o2, 64), t1 = __shfl_down(imax, o2, 64);
         imin = t0 < imin ? t0 : imin; imax = t1 > imax ? t1 : imax;
     }
-    if ((threadIdx.x & 63) == 0 && a[0]) {
+    pc1 = wave_sum_u32(pc1); pc2 = wave_sum_u32(pc2); pc3 = wave_sum_u32(pc3);
+    eul = (int)wave_sum_u32((uint32_t)eul);
+    if ((threadIdx.x & 63) == 0) {
         unsigned long long *q = (unsigned long long *)(sums + (size_t)s * PSEG_NSUMS);
-        atomicAdd(&q[0], a[0]); atomicAdd(&q[1], a[1]); atomicAdd(&q[2], a[2]); atomicAdd(&q[3], a[3]);
-        atomicAdd(&q[4], a[4]); atomicAdd(&q[5], a[5]); atomicAdd(&q[8], a[6]);
-        atomicMin((long long *)&q[6], (long long)imin); atomicMax((long long *)&q[7], (long long)imax);
+        if (a[0]) {
+            atomicAdd(&q[0], a[0]); atomicAdd(&q[1], a[1]); atomicAdd(&q[2], a[2]); atomicAdd(&q[3], a[3]);
+            atomicAdd(&q[4], a[4]); atomicAdd(&q[5], a[5]); atomicAdd(&q[8], a[6]);
+            atomicMin((long long *)&q[6], (long long)imin); atomicMax((long long *)&q[7], (long long)imax);
+        }
+        if (pc1) atomicAdd(&q[10], (unsigned long long)pc1);
+        if (pc2) atomicAdd(&q[11], (unsigned long long)pc2);
+        if (pc3) atomicAdd(&q[12], (unsigned long long)pc3);
+        if (eul) atomicAdd(&q[13], (unsigned long long)(long long)eul);
     }
+}
+
+// Convex hull area (skimage convex_hull_image, morphology/convex_hull.py:73-145): hull of the +-0.5 "diamond"
+// points of the row-extremal pixels, then every pixel centre inside or on the hull.  In doubled coordinates
+// R = 2*row (+-1), X = 2*col (+-1) the hull's left chain is the lower convex envelope of L(R) and the right chain
+// the upper envelope of U(R); both are built by one lane with a monotone-chain stack in LDS (exact integers),
+// then the lanes count the pixel centres row by row.  Block of 64 threads per saved object.
+#define HULL_MAX_ROWS 2600
+__global__ __launch_bounds__(64) void k_convex(int n_saved, const int32_t *__restrict__ geo, const long long *__restrict__ row_off,
+                                               const int32_t *__restrict__ rowext, long long *sums)
+{
+    __shared__ int Lp[2 * HULL_MAX_ROWS + 2], Up[2 * HULL_MAX_ROWS + 2];     // profiles over R' = R + 1 = 0 .. 2h
+    __shared__ short stL[2 * HULL_MAX_ROWS + 2], stU[2 * HULL_MAX_ROWS + 2];
+    __shared__ int nL, nU;
+    const int s = blockIdx.x;
+    const int h = geo[8 * (size_t)s + 4];
+    long long *q = sums + (size_t)s * PSEG_NSUMS;
+    if (h > HULL_MAX_ROWS) { if (threadIdx.x == 0) q[14] = -1; return; }       // reported as NaN by the host
+    const int32_t *re = rowext + 2 * row_off[s];
+    const int np = 2 * h + 1;
+    for (int i = threadIdx.x; i < np; i += 64) {
+        // R' even (R = 2r-1 odd): touches rows r-1 and r through the points (2r-1, 2c); R' odd (R = 2r): (2r, 2c-+1)
+        int l, u;
+        if (i & 1) { int r = i >> 1; l = 2 * re[2 * r] - 1; u = 2 * re[2 * r + 1] + 1; }
+        else {
+            int r = i >> 1;                                  // rows r-1 and r
+            l = 0x7fffffff; u = -0x7fffffff;
+            if (r - 1 >= 0) { l = 2 * re[2 * (r - 1)]; u = 2 * re[2 * (r - 1) + 1]; }
+            if (r < h) { int l2 = 2 * re[2 * r], u2 = 2 * re[2 * r + 1]; l = l2 < l ? l2 : l; u = u2 > u ? u2 : u; }
+        }
+        Lp[i] = l; Up[i] = u;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int n = 0;
+        for (int i = 0; i < np; i++) {                      // lower envelope: keep only strictly convex turns
+            while (n >= 2) {
+                int a = stL[n - 2], b = stL[n - 1];
+                long long cr = (long long)(b - a) * (Lp[i] - Lp[a]) - (long long)(Lp[b] - Lp[a]) * (i - a);
+                if (cr <= 0) n--; else break;
+            }
+            stL[n++] = (short)i;
+        }
+        nL = n;
+        n = 0;
+        for (int i = 0; i < np; i++) {                      // upper envelope
+            while (n >= 2) {
+                int a = stU[n - 2], b = stU[n - 1];
+                long long cr = (long long)(b - a) * (Up[i] - Up[a]) - (long long)(Up[b] - Up[a]) * (i - a);
+                if (cr >= 0) n--; else break;
+            }
+            stU[n++] = (short)i;
+        }
+        nU = n;
+    }
+    __syncthreads();
+    unsigned long long cnt = 0;
+    for (int r = threadIdx.x; r < h; r += 64) {
+        const int i = 2 * r + 1;                            // R' of the pixel centres of row r
+        int lo = 0, hi = nL - 1;                            // segment [stL[lo], stL[lo+1]] containing i
+        while (hi - lo > 1) { int m = (lo + hi) >> 1; if (stL[m] <= i) lo = m; else hi = m; }
+        int a = stL[lo], b = stL[hi];
+        // left bound X >= La + (Lb-La)*(i-a)/(b-a)  ->  smallest even X = 2c
+        long long num = (long long)Lp[a] * (b - a) + (long long)(Lp[b] - Lp[a]) * (i - a), den = b - a;
+        long long twoden = 2 * den;
+        long long cmin = num >= 0 ? (num + twoden - 1) / twoden : -((-num) / twoden);      // ceil(num / (2 den))
+        lo = 0; hi = nU - 1;
+        while (hi - lo > 1) { int m = (lo + hi) >> 1; if (stU[m] <= i) lo = m; else hi = m; }
+        a = stU[lo]; b = stU[hi];
+        num = (long long)Up[a] * (b - a) + (long long)(Up[b] - Up[a]) * (i - a); den = b - a; twoden = 2 * den;
+        long long cmax = num >= 0 ? num / twoden : -((-num + twoden - 1) / twoden);          // floor(num / (2 den))
+        if (cmax >= cmin) cnt += (unsigned long long)(cmax - cmin + 1);
+    }
+    cnt = wave_sum_u64(cnt);
+    if (threadIdx.x == 0) q[14] = (long long)cnt;
 }
 __global__ void k_init_sums(long long *sums, int n_saved)
 {
@@ -878,7 +1023,7 @@ extern "C" int pseg_create(int device, int H, int W, int max_frames, pseg_ctx **
     if (!out) return PSEG_ERR_ARG;
     *out = nullptr;
     pseg_ctx *ctx = new pseg_ctx();
-    if (H < 2 || W < 64 || (W % 64) || H > 65535 || W > 32768 || max_frames < 1 || max_frames > 65535) {
+    if (H < 2 || W < 64 || (W % 64) || H > 65535 || W > 8192 || max_frames < 1 || max_frames > 65535) {
         delete ctx;
         return PSEG_ERR_ARG;
     }
@@ -1131,11 +1276,15 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
         if (h_tot[2] > 0x7fffffffLL) return fail(ctx, PSEG_ERR_CAPACITY, "too many crop bands");
         ENSURE(ctx->crops_raw, (size_t)h_tot[0]); ENSURE(ctx->crops_masked, (size_t)h_tot[0]); ENSURE(ctx->crops_mask, (size_t)h_tot[0]);
         ENSURE(ctx->sums, (size_t)n_saved * PSEG_NSUMS * 8);
+        ENSURE(ctx->maskbits, (size_t)h_tot[1] * 2 * 4);     // first / last column of every window row (convex hull input)
         hipLaunchKernelGGL(k_init_sums, dim3(nblocks((size_t)n_saved * PSEG_NSUMS)), dim3(256), 0, st, (long long *)ctx->sums.p, n_saved);
         hipLaunchKernelGGL(k_crops_sums, dim3((unsigned)h_tot[2]), dim3(256), 0, st, S, n_saved, (const int32_t *)geo,
                            (const long long *)ctx->crop_off.p, (const long long *)ctx->band_off.p, (const int32_t *)objflag,
                            cleaned, raw, (uint8_t *)ctx->crops_raw.p, (uint8_t *)ctx->crops_masked.p,
-                           (uint8_t *)ctx->crops_mask.p, (long long *)ctx->sums.p);
+                           (uint8_t *)ctx->crops_mask.p, (long long *)ctx->sums.p, (const long long *)ctx->bits_off.p,
+                           (int32_t *)ctx->maskbits.p);
+        hipLaunchKernelGGL(k_convex, dim3(n_saved), dim3(64), 0, st, n_saved, (const int32_t *)geo, (const long long *)ctx->bits_off.p,
+                           (const int32_t *)ctx->maskbits.p, (long long *)ctx->sums.p);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(ctx->ev[5], st));
@@ -1183,7 +1332,8 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
     }
     for (int s = 0; s < n_saved; s++) {
         int i = h_saved_row[s];
-        const int64_t *q = h_sums + (size_t)s * PSEG_NSUMS;
+        int64_t *q = h_sums + (size_t)s * PSEG_NSUMS;
+        q[9] = q[0];                                         // filled area (see FA below)
         double *p = h_props + (size_t)i * PSEG_NPROPS;
         const double w = hrows[6 * hr + i], h = hrows[7 * hr + i];
         const double N = (double)q[0];
@@ -1196,18 +1346,34 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
         if (l2 < 0) l2 = 0;
         const double major = 4 * sqrt(l1), minor = 4 * sqrt(l2);
         double orient = (a - c == 0) ? (b < 0 ? -M_PI / 4 : M_PI / 4) : 0.5 * atan2(-2 * b, c - a);
+        // detection.py:84-152 in emitted order; scikit-image definitions per SURVEY.md 8(a) R9-table
+        const double FA = N;            // filled_area: a window of hole-filled objects has no 8-connected holes
+        const double perim = (double)q[10] + (double)q[11] * sqrt(2.0) + (double)q[12] * ((1.0 + sqrt(2.0)) / 2.0);
+        const double meanI = q[8] / N;
+        const double conv = q[14] >= 0 ? (double)q[14] : NAN;
         p[0] = w; p[1] = h; p[2] = 0; p[3] = 0;
-        p[5] = N;
+        p[4] = (4 * M_PI * FA) / (perim * perim);          // circ.
+        p[5] = N;                                            // area_exc
+        p[6] = FA;                                           // area_rprops
+        p[7] = 1 - N / FA;                                   // %area
         p[8] = major; p[9] = minor; p[10] = cr; p[11] = cc;
-        p[13] = (double)q[6]; p[14] = (double)q[7]; p[15] = q[8] / N;
-        p[18] = major / minor;
-        p[19] = (double)(uint8_t)(q[7] - q[6]);
-        p[23] = orient / M_PI * 180 + 90;
-        p[24] = w * h;
-        p[25] = l1 == 0 ? 0 : sqrt(1 - l2 / l1);
-        p[26] = sqrt(4 * N / M_PI);
-        p[28] = N / (w * h);
-        p[29] = cc; p[30] = cr;
+        p[12] = conv;                                        // convex_area
+        p[13] = (double)q[6]; p[14] = (double)q[7]; p[15] = meanI;
+        p[16] = FA * meanI;                                  // intden
+        p[17] = perim;                                       // perim.
+        p[18] = major / minor;                               // elongation (inf / nan like np.divide)
+        p[19] = (double)(uint8_t)(q[7] - q[6]);              // range (uint8 arithmetic)
+        p[20] = perim / N;                                   // perimareaexc
+        p[21] = perim / major;                               // perimmajor
+        p[22] = (4 * M_PI * N) / (perim * perim);            // circex
+        p[23] = orient / M_PI * 180 + 90;                    // angle
+        p[24] = w * h;                                       // bounding_box_area
+        p[25] = l1 == 0 ? 0 : sqrt(1 - l2 / l1);             // eccentricity
+        p[26] = sqrt(4 * N / M_PI);                          // equivalent_diameter
+        p[27] = (double)q[13];                               // euler_number
+        p[28] = N / (w * h);                                 // extent
+        p[29] = cc; p[30] = cr;                              // local_centroid_col / _row
+        p[31] = N / conv;                                    // solidity
     }
     if (out) {
         memset(out, 0, sizeof(*out));

@@ -16,9 +16,8 @@ PROP_KEYS = [
 ]
 
 
-# columns the device does not produce yet (NaN in the table): SURVEY.md 8(f) N1
-PENDING_PROPS = {"circ.", "area_rprops", "%area", "convex_area", "intden", "perim.", "perimareaexc", "perimmajor",
-                 "circex", "euler_number", "solidity"}
+# every column is produced on the device (exact integer sums) and finished in float64 by the library
+PENDING_PROPS = set()
 
 
 class PsegError(RuntimeError):
