@@ -715,7 +715,8 @@ __host__ __device__ inline int crop_rows_per_band(int w)
     if (r > 1020) r = 1020;
     return r < 1 ? 1 : r;
 }
-__global__ void k_saved_geo(const uint32_t *n_saved_p, const int32_t *saved_row, RowsDev R, int32_t *geo, unsigned long long *sz)
+__global__ void k_saved_geo(const uint32_t *n_saved_p, const int32_t *saved_row, RowsDev R, int32_t *geo, unsigned long long *sz,
+                            long long *totals)
 {
     size_t g = GTID;
     if (g >= (size_t)*n_saved_p) return;
@@ -727,6 +728,7 @@ __global__ void k_saved_geo(const uint32_t *n_saved_p, const int32_t *saved_row,
     sz[3 * g] = (unsigned long long)w * h;
     sz[3 * g + 1] = (unsigned long long)h;                 // rows: offset of the object's per-row extremes
     sz[3 * g + 2] = (unsigned long long)((h + rpb - 1) / rpb);
+    if (h > totals[3]) atomicMax(&totals[3], (long long)h);    // tallest saved object: LDS size of k_convex
 }
 // exclusive scans of the three size columns by one block of 1024 threads; out[k][0..n]
 __global__ __launch_bounds__(1024) void k_scan_sizes(const unsigned long long *sz, const uint32_t *n_p, long long *crop_off,
@@ -937,74 +939,78 @@ __global__ __launch_bounds__(256) void k_crops_sums(SegState S, int n_saved, con
 // R = 2*row (+-1), X = 2*col (+-1) the hull's left chain is the lower convex envelope of L(R) and the right chain
 // the upper envelope of U(R); both are built by one lane with a monotone-chain stack in LDS (exact integers),
 // then the lanes count the pixel centres row by row.  Block of 64 threads per saved object.
-#define HULL_MAX_ROWS 2600
-__global__ __launch_bounds__(64) void k_convex(int n_saved, const int32_t *__restrict__ geo, const long long *__restrict__ row_off,
-                                               const int32_t *__restrict__ rowext, long long *sums)
+// Each chain is found by a wave-parallel gift-wrapping march: from the current vertex a, the next vertex is the
+// point of extreme slope among all later points (64 lanes scan + a wave reduction, exact 64-bit cross products;
+// ties go to the farthest point).  The rows spanned by the new hull edge get their column bound right away, so no
+// vertex list is stored.  Wave 0 walks the left chain, wave 1 the right chain.  Dynamic LDS: 16 bytes per row
+// (first / last column, left / right bound), sized by the tallest saved object of the batch.
+template <bool LOWER>
+__device__ __forceinline__ void hull_march(const int *fl, int h, int *bound, int lane)
 {
-    __shared__ int Lp[2 * HULL_MAX_ROWS + 2], Up[2 * HULL_MAX_ROWS + 2];     // profiles over R' = R + 1 = 0 .. 2h
-    __shared__ short stL[2 * HULL_MAX_ROWS + 2], stU[2 * HULL_MAX_ROWS + 2];
-    __shared__ int nL, nU;
+    const int np = 2 * h + 1;
+    // profile over R' = R + 1: odd R' = pixel row r (points (2r, 2c -+ 1)), even R' = between rows r-1 and r ((2r-1, 2c))
+    auto prof = [&](int i) -> int {
+        const int r = i >> 1, k = LOWER ? 0 : 1;
+        if (i & 1) return LOWER ? 2 * fl[2 * r] - 1 : 2 * fl[2 * r + 1] + 1;
+        int va = r - 1 >= 0 ? 2 * fl[2 * (r - 1) + k] : (LOWER ? 0x3fffffff : -0x3fffffff);
+        int vb = r < h ? 2 * fl[2 * r + k] : (LOWER ? 0x3fffffff : -0x3fffffff);
+        return LOWER ? (va < vb ? va : vb) : (va > vb ? va : vb);
+    };
+    int a = 0, va = prof(0);
+    while (a < np - 1) {
+        int bj = -1, bv = 0;
+        for (int j = a + 1 + lane; j < np; j += 64) {
+            int v = prof(j);
+            if (bj < 0) { bj = j; bv = v; }
+            else {
+                long long d = (long long)(v - va) * (bj - a) - (long long)(bv - va) * (j - a);
+                if (LOWER ? d <= 0 : d >= 0) { bj = j; bv = v; }      // j > bj: a tie goes to the farther point
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            int oj = __shfl_xor(bj, o, 64), ov = __shfl_xor(bv, o, 64);
+            if (oj >= 0) {
+                bool take = bj < 0;
+                if (!take) {
+                    long long d = (long long)(ov - va) * (bj - a) - (long long)(bv - va) * (oj - a);
+                    take = LOWER ? (d < 0 || (d == 0 && oj > bj)) : (d > 0 || (d == 0 && oj > bj));
+                }
+                if (take) { bj = oj; bv = ov; }
+            }
+        }
+        const int b = bj, vb = bv;                          // the same in every lane
+        const long long den = b - a, twoden = 2 * den;
+        for (int i = (a | 1) + 2 * lane; i <= b; i += 128) {  // pixel rows (odd R') on the new edge (a, b]
+            if (i <= a) continue;
+            long long num = (long long)va * den + (long long)(vb - va) * (i - a);
+            long long c = LOWER ? (num >= 0 ? (num + twoden - 1) / twoden : -((-num) / twoden))     // ceil(num / (2 den))
+                                : (num >= 0 ? num / twoden : -((-num + twoden - 1) / twoden));      // floor(num / (2 den))
+            bound[i >> 1] = (int)c;
+        }
+        a = b; va = vb;
+    }
+}
+__global__ __launch_bounds__(128) void k_convex(int n_saved, const int32_t *__restrict__ geo, const long long *__restrict__ row_off,
+                                                const int32_t *__restrict__ rowext, long long *sums, int hmax)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char hull_smem[];
+    int *fl = (int *)hull_smem;                             // first / last column per row
+    int *cmin = fl + 2 * hmax, *cmax = cmin + hmax;
     const int s = blockIdx.x;
     const int h = geo[8 * (size_t)s + 4];
     long long *q = sums + (size_t)s * PSEG_NSUMS;
-    if (h > HULL_MAX_ROWS) { if (threadIdx.x == 0) q[14] = -1; return; }       // reported as NaN by the host
     const int32_t *re = rowext + 2 * row_off[s];
-    const int np = 2 * h + 1;
-    for (int i = threadIdx.x; i < np; i += 64) {
-        // R' even (R = 2r-1 odd): touches rows r-1 and r through the points (2r-1, 2c); R' odd (R = 2r): (2r, 2c-+1)
-        int l, u;
-        if (i & 1) { int r = i >> 1; l = 2 * re[2 * r] - 1; u = 2 * re[2 * r + 1] + 1; }
-        else {
-            int r = i >> 1;                                  // rows r-1 and r
-            l = 0x7fffffff; u = -0x7fffffff;
-            if (r - 1 >= 0) { l = 2 * re[2 * (r - 1)]; u = 2 * re[2 * (r - 1) + 1]; }
-            if (r < h) { int l2 = 2 * re[2 * r], u2 = 2 * re[2 * r + 1]; l = l2 < l ? l2 : l; u = u2 > u ? u2 : u; }
-        }
-        Lp[i] = l; Up[i] = u;
-    }
+    for (int i = threadIdx.x; i < 2 * h; i += 128) fl[i] = re[i];
     __syncthreads();
-    if (threadIdx.x == 0) {
-        int n = 0;
-        for (int i = 0; i < np; i++) {                      // lower envelope: keep only strictly convex turns
-            while (n >= 2) {
-                int a = stL[n - 2], b = stL[n - 1];
-                long long cr = (long long)(b - a) * (Lp[i] - Lp[a]) - (long long)(Lp[b] - Lp[a]) * (i - a);
-                if (cr <= 0) n--; else break;
-            }
-            stL[n++] = (short)i;
-        }
-        nL = n;
-        n = 0;
-        for (int i = 0; i < np; i++) {                      // upper envelope
-            while (n >= 2) {
-                int a = stU[n - 2], b = stU[n - 1];
-                long long cr = (long long)(b - a) * (Up[i] - Up[a]) - (long long)(Up[b] - Up[a]) * (i - a);
-                if (cr >= 0) n--; else break;
-            }
-            stU[n++] = (short)i;
-        }
-        nU = n;
-    }
+    if (threadIdx.x < 64) hull_march<true>(fl, h, cmin, threadIdx.x);
+    else hull_march<false>(fl, h, cmax, threadIdx.x - 64);
     __syncthreads();
     unsigned long long cnt = 0;
-    for (int r = threadIdx.x; r < h; r += 64) {
-        const int i = 2 * r + 1;                            // R' of the pixel centres of row r
-        int lo = 0, hi = nL - 1;                            // segment [stL[lo], stL[lo+1]] containing i
-        while (hi - lo > 1) { int m = (lo + hi) >> 1; if (stL[m] <= i) lo = m; else hi = m; }
-        int a = stL[lo], b = stL[hi];
-        // left bound X >= La + (Lb-La)*(i-a)/(b-a)  ->  smallest even X = 2c
-        long long num = (long long)Lp[a] * (b - a) + (long long)(Lp[b] - Lp[a]) * (i - a), den = b - a;
-        long long twoden = 2 * den;
-        long long cmin = num >= 0 ? (num + twoden - 1) / twoden : -((-num) / twoden);      // ceil(num / (2 den))
-        lo = 0; hi = nU - 1;
-        while (hi - lo > 1) { int m = (lo + hi) >> 1; if (stU[m] <= i) lo = m; else hi = m; }
-        a = stU[lo]; b = stU[hi];
-        num = (long long)Up[a] * (b - a) + (long long)(Up[b] - Up[a]) * (i - a); den = b - a; twoden = 2 * den;
-        long long cmax = num >= 0 ? num / twoden : -((-num + twoden - 1) / twoden);          // floor(num / (2 den))
-        if (cmax >= cmin) cnt += (unsigned long long)(cmax - cmin + 1);
-    }
+    for (int r = threadIdx.x; r < h; r += 128)
+        if (cmax[r] >= cmin[r]) cnt += (unsigned long long)(cmax[r] - cmin[r] + 1);
     cnt = wave_sum_u64(cnt);
-    if (threadIdx.x == 0) q[14] = (long long)cnt;
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd((unsigned long long *)&q[14], cnt);
 }
 __global__ void k_init_sums(long long *sums, int n_saved)
 {
@@ -1243,11 +1249,12 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
     int32_t *geo = (int32_t *)ctx->saved_geo.p;
     unsigned long long *sz = (unsigned long long *)(geo + 8 * scap);
     long long *totals = (long long *)ctx->totals.p;
+    HIPCHK(hipMemsetAsync(totals, 0, 4 * 8, st));
     if (nfg > 0) {
         hipLaunchKernelGGL(k_emit, dim3(nblocks(nfg)), dim3(256), 0, st, S, nfg, min_seg, min_save, (const uint32_t *)ftot3,
                            (const uint32_t *)rowbase, (const uint32_t *)savedbase, R, objlabel, objflag, saved_row);
         hipLaunchKernelGGL(k_saved_geo, dim3(nblocks(nfg)), dim3(256), 0, st, (const uint32_t *)(savedbase + n),
-                           (const int32_t *)saved_row, R, geo, sz);
+                           (const int32_t *)saved_row, R, geo, sz, totals);
     }
     hipLaunchKernelGGL(k_scan_sizes, dim3(1), dim3(1024), 0, st, (const unsigned long long *)sz, (const uint32_t *)(savedbase + n),
                        (long long *)ctx->crop_off.p, (long long *)ctx->bits_off.p, (long long *)ctx->band_off.p, totals);
@@ -1261,8 +1268,8 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
     if (mask) HIPCHK(hipMemcpyAsync(&h_maskcnt, ctx->maskcnt.p, 8, hipMemcpyDeviceToHost, st));
     std::vector<uint8_t> hvalid(n);
     HIPCHK(hipMemcpyAsync(hvalid.data(), ctx->valid_dev.p, n, hipMemcpyDeviceToHost, st));
-    long long h_tot[3] = {0, 0, 0};
-    HIPCHK(hipMemcpyAsync(h_tot, totals, 3 * 8, hipMemcpyDeviceToHost, st));
+    long long h_tot[4] = {0, 0, 0, 0};
+    HIPCHK(hipMemcpyAsync(h_tot, totals, 4 * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipEventRecord(ctx->ev[3], st));
     if (labels) {
         hipLaunchKernelGGL(k_label_fill, dim3(nblocks(P / 4), n), dim3(256), 0, st, S, (const int32_t *)objlabel, labels);
@@ -1283,8 +1290,13 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
                            cleaned, raw, (uint8_t *)ctx->crops_raw.p, (uint8_t *)ctx->crops_masked.p,
                            (uint8_t *)ctx->crops_mask.p, (long long *)ctx->sums.p, (const long long *)ctx->bits_off.p,
                            (int32_t *)ctx->maskbits.p);
-        hipLaunchKernelGGL(k_convex, dim3(n_saved), dim3(64), 0, st, n_saved, (const int32_t *)geo, (const long long *)ctx->bits_off.p,
-                           (const int32_t *)ctx->maskbits.p, (long long *)ctx->sums.p);
+        const int hmax = (int)h_tot[3];
+        const size_t hull_lds = (size_t)hmax * 16 + 16;
+        if (hull_lds > 150 * 1024) return fail(ctx, PSEG_ERR_CAPACITY, "saved object too tall for the convex-hull kernel");
+        if (hull_lds > 48 * 1024)
+            HIPCHK(hipFuncSetAttribute((const void *)k_convex, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hull_lds));
+        hipLaunchKernelGGL(k_convex, dim3(n_saved), dim3(128), hull_lds, st, n_saved, (const int32_t *)geo,
+                           (const long long *)ctx->bits_off.p, (const int32_t *)ctx->maskbits.p, (long long *)ctx->sums.p, hmax);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(ctx->ev[5], st));
