@@ -1,0 +1,140 @@
+"""Detection stage with the reference's call signatures (/root/reference/detection.py), computed by
+libpiscoseg.so on the GPU.  PNG / CSV writing stays on the host (I/O, detection.py:251-253,293)."""
+import csv
+import os
+import threading
+import time
+from concurrent.futures import ThreadPoolExecutor
+from dataclasses import dataclass
+
+import numpy as np
+
+from .bg_correction import _segmenter
+from .engine import PROP_KEYS
+
+# columns of regionprop2zooprocess that the reference emits as integers (ints / numpy ints / uint8)
+_INT_PROPS = {"width", "height", "bx", "by", "area_exc", "area_rprops", "convex_area", "min_intensity", "max_intensity",
+              "range", "bounding_box_area", "euler_number"}
+
+
+@dataclass
+class DetectionSettings:
+    """detection.py:22-58 (same fields, same order)."""
+    data_path: str
+    raw_crop_path: str
+    deconv_crop_path: str
+    mask_path: str
+    img_path: str
+    min_area_to_save: float
+    min_area_to_segment: float
+    n_sigma: float
+    save_bb_image: bool
+    save_crops: bool
+    equalize_hist: bool
+    resize: bool
+    clear_save_path: bool
+    mask_img: bool
+    mask_radius: int
+
+
+def save_crop_data(path, data):
+    """detection.py:61-73."""
+    with open(path, "w", newline="") as f:
+        csv.writer(f, delimiter=",").writerows(data)
+
+
+def disk_mask(settings, shape=(2560, 2560), device=0):
+    """The mask run_detection builds once per batch (detection.py:315-326); a device tensor."""
+    import torch
+    seg = _segmenter(shape[0], shape[1], 1, device)
+    if settings.mask_img:
+        return seg.disk_mask(settings.mask_radius)
+    return torch.zeros(shape, dtype=torch.uint8, device=f"cuda:{device}")
+
+
+def rows_of_frame(tab, f, fn, mean_raw):
+    """The crop_data list of detect_on_img for frame f (detection.py:265,271): 44 entries per kept object with the
+    reference's value types (ints for saved boxes, centre floats for unsaved ones, nan padding)."""
+    rows = []
+    a, b = int(tab.frame_row_offset[f]), int(tab.frame_row_offset[f + 1])
+    for i in range(a, b):
+        c = int(tab.c[i])
+        name = f"{fn[:-4]}_{c}.png"
+        x, y, w, h = int(tab.x[i]), int(tab.y[i]), int(tab.w[i]), int(tab.h[i])
+        head = [c, name, mean_raw[0], mean_raw[1], float(tab.frame_mean[f]), float(tab.frame_std[f]), float(tab.area[i])]
+        if tab.saved[i]:
+            props = [int(v) if k in _INT_PROPS else float(v) for k, v in zip(PROP_KEYS, tab.props[i])]
+            rows.append(head + [x, y, w, h, 1] + props)
+        else:
+            rows.append(head + [x + w / 2, y + h / 2, float(w), float(h), 0] + [np.nan] * 32)
+    return rows
+
+
+def _write_frame(tab, f, fn, mean_raw, settings, saved_of_row):
+    from PIL import Image
+    if not tab.frame_valid[f]:                                           # detection.py:294-297
+        save_crop_data(os.path.join(settings.data_path, fn[:-4] + ".csv"), ["corrupt image!"])
+        return
+    rows = rows_of_frame(tab, f, fn, mean_raw)
+    if settings.save_crops:
+        a = int(tab.frame_row_offset[f])
+        for k, row in enumerate(rows):
+            if row[11] != 1:
+                continue
+            s = saved_of_row[a + k]
+            Image.fromarray(tab.crop(s, "masked")).save(os.path.join(settings.deconv_crop_path, row[1]))   # :251
+            Image.fromarray(tab.crop(s, "raw")).save(os.path.join(settings.raw_crop_path, row[1]))         # :252
+            Image.fromarray(tab.crop(s, "mask")).save(os.path.join(settings.mask_path, row[1]))            # :253
+    save_crop_data(os.path.join(settings.data_path, fn[:-4] + ".csv"), rows)                               # :293
+
+
+def detect_batch(items, settings, mask, n_writers=8, device=0):
+    """All frames of a batch in one library call + host-side file writing.  ``items`` are the tuples of the
+    background stage; ``mask`` is the uint8 disk mask (numpy array or device tensor)."""
+    import torch
+    dev = f"cuda:{device}"
+    good = [it for it in items if not isinstance(it[1], list)]
+    for it in items:
+        if isinstance(it[1], list):                                      # corrupt frame (detection.py:294-297)
+            save_crop_data(os.path.join(settings.data_path, it[3][:-4] + ".csv"), ["corrupt image!"])
+    if not good:
+        return None
+    def dev_stack(k):
+        if torch.is_tensor(good[0][k]):
+            return torch.stack([it[k] for it in good]).contiguous()
+        return torch.from_numpy(np.stack([it[k] for it in good])).to(dev)
+    cleaned = dev_stack(1)
+    raw = cleaned if all(it[0] is it[1] for it in good) else dev_stack(0)
+    H, W = cleaned.shape[-2:]
+    seg = _segmenter(H, W, len(good), device)
+    m = None
+    if settings.mask_img and mask is not None:
+        m = mask if torch.is_tensor(mask) else torch.from_numpy(np.ascontiguousarray(mask)).to(dev)
+    valid = np.array([1 if it[2][1] > 2 else 0 for it in good], np.uint8)          # detection.py:179
+    tab = seg.detect(cleaned, raw=raw, mask=m, valid=valid, threshold=10,
+                     min_area_to_segment=settings.min_area_to_segment, min_area_to_save=settings.min_area_to_save,
+                     fetch_crops=settings.save_crops)
+    saved_of_row = {int(r): s for s, r in enumerate(tab.saved_row)}
+    with ThreadPoolExecutor(max_workers=max(1, n_writers)) as ex:
+        list(ex.map(lambda f: _write_frame(tab, f, good[f][3], good[f][2], settings, saved_of_row), range(len(good))))
+    return tab
+
+
+def detect_on_img(input, settings, mask, index=0):
+    """detection.py:162-297 for one frame."""
+    detect_batch([input], settings, mask, n_writers=1)
+
+
+def run_detection(input, settings, n_cores, n_imgs, running):
+    """detection.py:300-344: takes n_imgs items from the queue and blocks until every file is written."""
+    mask = disk_mask(settings) if settings.mask_img else None
+    items = []
+    for i in range(n_imgs):
+        task = input.get()
+        items.append(task)
+        print(i, task[-1])
+    H = next((it[1].shape[0] for it in items if not isinstance(it[1], list)), 2560)
+    if mask is not None and mask.shape[0] != H:
+        mask = disk_mask(settings, shape=(H, H))
+    detect_batch(items, settings, mask, n_writers=n_cores)
+    print("detection finished")

@@ -1,0 +1,93 @@
+"""Drop-in stage functions (reference signatures) on the GPU: files written by run_detection are compared with
+the oracle's rows and crops."""
+import csv
+import os
+from queue import Queue
+
+import numpy as np
+import pytest
+
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+def _parse(v):
+    try:
+        return float(v)
+    except ValueError:
+        return v
+
+
+def test_stage_functions_write_reference_files(tmp_path):
+    from PIL import Image
+    from imageprocessing_amd import bg_correction, detection, reader, synth
+    H = W = 256
+    n = 14
+    objs, off = synth.make_objects(n, H, W, 21, per_frame=10, dmin=40, dmax=700)
+    stack = synth.render(n, H, W, 21, objs, off)
+    stack[5] = 50                                            # corrupt frame
+    names = [f"SO298_{i:04d}_img.png" for i in range(n)]
+    out = reader.ReaderOutput(n)
+    for i in range(n):
+        out.add_output(stack[i], names[i], i)
+    q = Queue()
+    bg_correction.run_bg_correction(out, q, 6, None).join()
+    assert q.qsize() == n
+    dirs = {k: str(tmp_path / k) for k in ("Data", "Crops", "Deconv_crops", "Masks", "Images")}
+    for d in dirs.values():
+        os.makedirs(d)
+    radius = 120
+    settings = detection.DetectionSettings(dirs["Data"], dirs["Crops"], dirs["Deconv_crops"], dirs["Masks"], dirs["Images"],
+                                           400, 10, 1, False, True, True, False, True, True, radius)
+    mask = helpers.make_disk(H, W, radius)
+    # run_detection builds its 2560x2560 mask from settings; for this small frame size the batch function is called
+    items = [q.get() for _ in range(n)]
+    detection.detect_batch(items, settings, mask, n_writers=4)
+    # oracle
+    o_items = helpers.oracle_bgcorrect(stack)
+    for it, name in zip(o_items, names):
+        it_named = (it[0], it[1], it[2], name)
+        det = helpers.oracle_detect([it_named], mask, want_labels=False)[0]
+        path = os.path.join(dirs["Data"], name[:-4] + ".csv")
+        got = list(csv.reader(open(path)))
+        if det["corrupt"]:
+            assert got == [list("corrupt image!")]          # csv.writer splits the string into characters (detection.py:297)
+            continue
+        assert len(got) == len(det["rows"])
+        for grow, orow in zip(got, det["rows"]):
+            assert len(grow) == 44
+            assert grow[1] == orow[1]
+            assert int(grow[0]) == orow[0] and int(grow[11]) == orow[11]
+            for j in list(range(2, 11)) + list(range(12, 44)):
+                g, o = _parse(grow[j]), float(orow[j])
+                if np.isnan(o):
+                    assert grow[j] == "nan"
+                else:
+                    np.testing.assert_allclose(g, o, rtol=1e-5, atol=1e-7)
+            if orow[11]:
+                assert "." not in grow[7] and "." not in grow[12] and "." not in grow[25]     # ints print as ints
+            else:
+                assert "." in grow[7]                                                          # centre floats (detection.py:271)
+        for c, masked, raw, cmask in det["crops"]:
+            fn = f"{name[:-4]}_{c}.png"
+            assert np.array_equal(np.asarray(Image.open(os.path.join(dirs["Deconv_crops"], fn))), masked)
+            assert np.array_equal(np.asarray(Image.open(os.path.join(dirs["Crops"], fn))), raw)
+            assert np.array_equal(np.asarray(Image.open(os.path.join(dirs["Masks"], fn))), cmask)
+
+
+def test_correct_img_single_index():
+    from imageprocessing_amd import bg_correction, reader
+    rng = np.random.default_rng(3)
+    n, H, W = 17, 64, 64
+    stack = rng.integers(0, 256, (n, H, W), dtype=np.uint8)
+    out = reader.ReaderOutput(n)
+    for i in range(n):
+        out.add_output(stack[i], f"f{i}.png", i)
+    want = helpers.oracle_bgcorrect(stack)
+    for i in (0, 4, 5, 11, 16):
+        q = Queue()
+        bg_correction.correct_img(i, out, q, 6)
+        got = q.get()
+        assert np.array_equal(got[1], want[i][1])
+        np.testing.assert_allclose(got[2], want[i][2], rtol=1e-9)
