@@ -33,6 +33,11 @@ struct HostBuf {
     template <class T> T *as(size_t n) { if (v.size() < n * sizeof(T)) v.resize(n * sizeof(T)); return (T *)v.data(); }
 };
 
+struct PinBuf {             // page-locked host memory: D2H copies into it are single DMA transfers, no staging
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+
 struct RowsDev {           // device SoA of the kept-object rows
     int32_t *frame, *c, *label, *area2, *x, *y, *w, *h, *saved, *root;
 };
@@ -46,20 +51,27 @@ struct pseg_ctx {
     hipEvent_t ev[8] = {};
     float ms[6] = {};
     // dense workspaces
-    DevBuf bits, partials, fsums, valid_dev, maskcnt, rowspans;
+    DevBuf bits, partials, rowspans;
+    // head arena: every small per-frame table the host needs, contiguous so that ONE copy fetches it.
+    // fsums / valid_dev / maskcnt / totals / ftot are views into it (head_setup), not allocations.
+    DevBuf head, fsums, valid_dev, maskcnt, totals, ftot;
+    size_t head_copy_off = 0, head_copy_bytes = 0;
+    int head_n = -1;
+    PinBuf pin_head, pin_tail, pin_nfg;
+    DevBuf outpack;               // sums | crop_off | rows (10 columns) | saved_row, packed for ONE copy to pin_tail
+    bool head_on_host = false;    // pin_head holds this call's head (pseg_process reuses it for the raw statistics)
     // sparse workspaces
-    DevBuf rowcnt, rowoff, framebase, ftot;      // ftot: per-frame totals {next, nkept, nsaved} and bases
+    DevBuf rowcnt, rowoff, framebase;
     DevBuf run_x, run_fy, fg_parent, ext, bg_parent, bg_left, minx, maxx, maxy, area2, extrank,
         keptrank, savedrank, objlabel, objflag;
-    DevBuf rows, saved_row, saved_geo, crop_off, bits_off, maskbits, sums, crops_raw, crops_masked, crops_mask, totals;
+    DevBuf rows, saved_row, saved_geo, crop_off, bits_off, maskbits, crops_raw, crops_masked, crops_mask;
     bool have_bits = false;       // threshold plane + masked sums already produced by the bg kernel
     DevBuf bounds, band_off, trash;
     int bounds_n = -1, bounds_chunks = -1;
     int bg_chunks = 1;            // time chunks of the streaming background kernel (PSEG_BG_CHUNKS)
     bool force_generic = false;   // PSEG_BG_GENERIC=1: use the 12x-read reference kernel (debug / cross-check)
     // host results
-    HostBuf h_frame_row_offset, h_frame_n_contours, h_frame_valid, h_frame_mean, h_frame_std, h_rows, h_area,
-        h_saved8, h_props, h_saved_row, h_crop_off, h_sums, h_tmp;
+    HostBuf h_frame_row_offset, h_frame_n_contours, h_frame_valid, h_frame_mean, h_frame_std, h_area, h_saved8, h_props;
     int64_t crop_bytes = 0;
     int n_saved = 0;
 };
@@ -87,6 +99,59 @@ static int ensure(pseg_ctx *ctx, DevBuf &b, size_t bytes)
     return 0;
 }
 #define ENSURE(buf, bytes) do { int r_ = ensure(ctx, (buf), (bytes)); if (r_) return r_; } while (0)
+
+static int ensure_pin(pseg_ctx *ctx, PinBuf &b, size_t bytes)
+{
+    if (bytes <= b.bytes) return 0;
+    if (b.p) HIPCHK(hipHostFree(b.p));
+    b.p = nullptr; b.bytes = 0;
+    size_t want = bytes + bytes / 4 + 256;
+    HIPCHK(hipHostMalloc(&b.p, want, hipHostMallocDefault));
+    b.bytes = want;
+    return 0;
+}
+#define ENSURE_PIN(buf, bytes) do { int r_ = ensure_pin(ctx, (buf), (bytes)); if (r_) return r_; } while (0)
+
+// head arena for a batch of n frames (u32 words unless noted):
+//   ftot [n] | ftot3 [3n] rowbase [n+1] savedbase [n+1] | pad | fsums [4n] u64 | maskcnt u64 | totals [4] i64 | valid [n] u8
+// everything from ftot3 on is what the host reads back (one copy of head_copy_bytes from head_copy_off)
+static int head_setup(pseg_ctx *ctx, int n)
+{
+    if (ctx->head_n == n) return 0;
+    size_t o_ftot = 0, o_ftot3 = (size_t)n * 4, o_end32 = o_ftot3 + ((size_t)5 * n + 2) * 4;
+    size_t o_fsums = (o_end32 + 7) & ~(size_t)7, o_maskcnt = o_fsums + (size_t)n * 32, o_totals = o_maskcnt + 8;
+    size_t o_valid = o_totals + 32, o_end = o_valid + (size_t)n;
+    ENSURE(ctx->head, o_end + 64);
+    ENSURE_PIN(ctx->pin_head, o_end - o_ftot3 + 64);
+    ENSURE_PIN(ctx->pin_nfg, 64);
+    char *b = (char *)ctx->head.p;
+    ctx->ftot.p = b + o_ftot; ctx->fsums.p = b + o_fsums; ctx->maskcnt.p = b + o_maskcnt; ctx->totals.p = b + o_totals;
+    ctx->valid_dev.p = b + o_valid;
+    ctx->head_copy_off = o_ftot3; ctx->head_copy_bytes = o_end - o_ftot3;
+    ctx->head_n = n;
+    return 0;
+}
+// host view of the copied head
+struct HeadHost {
+    const uint32_t *ftot3, *rowbase, *savedbase;
+    const uint64_t *fsums;
+    uint64_t maskcnt;
+    const long long *totals;
+    const uint8_t *valid;
+};
+static HeadHost head_host(const pseg_ctx *ctx, int n)
+{
+    const char *b = (const char *)ctx->pin_head.p;            // b[0] corresponds to head offset head_copy_off
+    size_t o_end32 = ((size_t)5 * n + 2) * 4 + (size_t)n * 4;
+    size_t o_fsums = ((o_end32 + 7) & ~(size_t)7) - ctx->head_copy_off;
+    HeadHost h;
+    h.ftot3 = (const uint32_t *)b; h.rowbase = h.ftot3 + 3 * (size_t)n; h.savedbase = h.rowbase + (n + 1);
+    h.fsums = (const uint64_t *)(b + o_fsums);
+    h.maskcnt = *(const uint64_t *)(b + o_fsums + (size_t)n * 32);
+    h.totals = (const long long *)(b + o_fsums + (size_t)n * 32 + 8);
+    h.valid = (const uint8_t *)(b + o_fsums + (size_t)n * 32 + 40);
+    return h;
+}
 
 // ------------------------------------------------------------------------------------------------
 // small device helpers
@@ -1050,13 +1115,14 @@ extern "C" int pseg_destroy(pseg_ctx *ctx)
     if (!ctx) return PSEG_ERR_ARG;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
-    DevBuf *bufs[] = {&ctx->bits, &ctx->partials, &ctx->fsums, &ctx->valid_dev, &ctx->maskcnt, &ctx->rowspans, &ctx->rowcnt,
-                      &ctx->rowoff, &ctx->framebase, &ctx->ftot, &ctx->run_x, &ctx->run_fy, &ctx->fg_parent, &ctx->ext,
+    DevBuf *bufs[] = {&ctx->bits, &ctx->partials, &ctx->head, &ctx->outpack, &ctx->rowspans, &ctx->rowcnt,
+                      &ctx->rowoff, &ctx->framebase, &ctx->run_x, &ctx->run_fy, &ctx->fg_parent, &ctx->ext,
                       &ctx->bg_parent, &ctx->bg_left, &ctx->minx, &ctx->maxx, &ctx->maxy, &ctx->area2,
                       &ctx->extrank, &ctx->keptrank, &ctx->savedrank, &ctx->objlabel, &ctx->objflag, &ctx->rows,
-                      &ctx->saved_row, &ctx->saved_geo, &ctx->crop_off, &ctx->bits_off, &ctx->maskbits, &ctx->sums,
-                      &ctx->crops_raw, &ctx->crops_masked, &ctx->crops_mask, &ctx->totals, &ctx->bounds, &ctx->band_off, &ctx->trash};
+                      &ctx->saved_row, &ctx->saved_geo, &ctx->crop_off, &ctx->bits_off, &ctx->maskbits,
+                      &ctx->crops_raw, &ctx->crops_masked, &ctx->crops_mask, &ctx->bounds, &ctx->band_off, &ctx->trash};
     for (DevBuf *b : bufs) if (b->p) hipFree(b->p);
+    for (PinBuf *b : {&ctx->pin_head, &ctx->pin_tail, &ctx->pin_nfg}) if (b->p) hipHostFree(b->p);
     for (auto &e : ctx->ev) if (e) hipEventDestroy(e);
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -1095,8 +1161,7 @@ static int run_bg(pseg_ctx *ctx, const uint8_t *frames, int n, int n_bg_imgs, co
     unsigned npart = stream ? nblk * 4 : nblk;               // partial sums per frame: per wave / per block
     ENSURE(ctx->bits, (size_t)n * P / 8);
     ENSURE(ctx->partials, (size_t)n * npart * 4 * sizeof(uint32_t));
-    ENSURE(ctx->fsums, (size_t)n * 4 * sizeof(uint64_t));
-    ENSURE(ctx->valid_dev, (size_t)n);
+    { int r_ = head_setup(ctx, n); if (r_) return r_; }
     int chunks = 1;
     if (stream) {
         ENSURE(ctx->trash, P + P / 8 + (size_t)npart * 16 + 256);
@@ -1138,16 +1203,24 @@ static void finish_meanstd(const uint64_t *s, double cnt, double *mean, double *
     *std_ = sqrt(var < 0 ? 0 : var);
 }
 
+static int fetch_head(pseg_ctx *ctx)
+{
+    HIPCHK(hipMemcpyAsync(ctx->pin_head.p, (const char *)ctx->head.p + ctx->head_copy_off, ctx->head_copy_bytes,
+                          hipMemcpyDeviceToHost, ctx->stream));
+    return 0;
+}
+
 static int fetch_raw_stats(pseg_ctx *ctx, int n, double *mean_std, uint8_t *valid)
 {
-    uint64_t *hs = ctx->h_tmp.as<uint64_t>((size_t)n * 4 + n);
-    uint8_t *hv = (uint8_t *)(hs + (size_t)n * 4);
-    HIPCHK(hipMemcpyAsync(hs, ctx->fsums.p, (size_t)n * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(hv, ctx->valid_dev.p, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (!ctx->head_on_host) {
+        int r = fetch_head(ctx);
+        if (r) return r;
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    HeadHost hh = head_host(ctx, n);
     for (int f = 0; f < n; f++) {
-        if (mean_std) finish_meanstd(hs + 4 * f, (double)ctx->P, &mean_std[2 * f], &mean_std[2 * f + 1]);
-        if (valid) valid[f] = hv[f];
+        if (mean_std) finish_meanstd(hh.fsums + 4 * f, (double)ctx->P, &mean_std[2 * f], &mean_std[2 * f + 1]);
+        if (valid) valid[f] = hh.valid[f];
     }
     return 0;
 }
@@ -1159,12 +1232,28 @@ extern "C" int pseg_bgcorrect(pseg_ctx *ctx, const uint8_t *frames, int n, int n
     if (r) return r;
     if (!frames || !cleaned) return fail(ctx, PSEG_ERR_ARG, "null frame pointer");
     ctx->have_bits = false;
+    ctx->head_on_host = false;
     r = run_bg(ctx, frames, n, n_bg_imgs, nullptr, 255, cleaned);
     if (r) return r;
     r = fetch_raw_stats(ctx, n, mean_std, valid);
     if (r) return r;
     HIPCHK(hipEventElapsedTime(&ctx->ms[0], ctx->ev[0], ctx->ev[1]));
     return PSEG_OK;
+}
+
+// rows (10 columns of stride rcap -> stride n_rows), saved_row and crop_off into the packed output arena
+__global__ __launch_bounds__(256) void k_pack_out(const int32_t *__restrict__ rows, size_t rcap, int n_rows,
+                                                  const int32_t *__restrict__ saved_row, const long long *__restrict__ crop_off,
+                                                  int n_saved, int32_t *__restrict__ o_rows, int32_t *__restrict__ o_saved_row,
+                                                  long long *__restrict__ o_crop_off)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n_rows) {
+#pragma unroll
+        for (int k = 0; k < 10; k++) o_rows[(size_t)k * n_rows + i] = rows[(size_t)k * rcap + i];
+    }
+    if (i < n_saved) o_saved_row[i] = saved_row[i];
+    if (i <= n_saved) o_crop_off[i] = crop_off[i];
 }
 
 // everything after the threshold plane exists.  valid flags are in ctx->valid_dev.
@@ -1182,25 +1271,24 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
     ENSURE(ctx->rowcnt, (size_t)n * H * 4);
     ENSURE(ctx->rowoff, (size_t)n * (H + 1) * 4);
     ENSURE(ctx->framebase, (size_t)(n + 1) * 4);
-    ENSURE(ctx->ftot, (size_t)(n + 1) * 4 * 8);
-    ENSURE(ctx->maskcnt, 64);
-    ENSURE(ctx->totals, 256);
+    { int r_ = head_setup(ctx, n); if (r_) return r_; }
     S.rowcnt = (uint32_t *)ctx->rowcnt.p; S.rowoff = (uint32_t *)ctx->rowoff.p; S.framebase = (uint32_t *)ctx->framebase.p;
     uint32_t *ftot = (uint32_t *)ctx->ftot.p;            // [n] run totals | [3n] rank totals | [n+1] rowbase | [n+1] savedbase
     uint32_t *ftot3 = ftot + n, *rowbase = ftot3 + 3 * (size_t)n, *savedbase = rowbase + (n + 1);
 
     HIPCHK(hipEventRecord(ctx->ev[2], st));
+    // maskcnt (8 B) and totals (32 B) are adjacent in the head arena: one clear; no mask = every pixel counts
+    HIPCHK(hipMemsetAsync(ctx->maskcnt.p, 0, 40, st));
     if (mask) {
-        HIPCHK(hipMemsetAsync(ctx->maskcnt.p, 0, 8, st));
         hipLaunchKernelGGL(k_mask_count, dim3(256), dim3(256), 0, st, mask, P, (unsigned long long *)ctx->maskcnt.p);
     }
     hipLaunchKernelGGL(k_runs<false>, dim3(nblocks((size_t)n * H, 4 * RUNS_RPW)), dim3(256), 0, st, S, n * H);
     hipLaunchKernelGGL(k_scan_rows, dim3(n), dim3(256), 0, st, S, ftot);
     hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(256), 0, st, (const uint32_t *)ftot, S.framebase, n, 1, 1);
     HIPCHK(hipGetLastError());
-    uint32_t nfg_u = 0;
-    HIPCHK(hipMemcpyAsync(&nfg_u, S.framebase + n, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(ctx->pin_nfg.p, S.framebase + n, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    const uint32_t nfg_u = *(const volatile uint32_t *)ctx->pin_nfg.p;
     if (nfg_u > 0x3fffffffu) return fail(ctx, PSEG_ERR_CAPACITY, "too many foreground runs");
     const int nfg = (int)nfg_u, nbg = nfg + n * H;
     const size_t cap = (size_t)(nfg > 0 ? nfg : 1);
@@ -1249,7 +1337,6 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
     int32_t *geo = (int32_t *)ctx->saved_geo.p;
     unsigned long long *sz = (unsigned long long *)(geo + 8 * scap);
     long long *totals = (long long *)ctx->totals.p;
-    HIPCHK(hipMemsetAsync(totals, 0, 4 * 8, st));
     if (nfg > 0) {
         hipLaunchKernelGGL(k_emit, dim3(nblocks(nfg)), dim3(256), 0, st, S, nfg, min_seg, min_save, (const uint32_t *)ftot3,
                            (const uint32_t *)rowbase, (const uint32_t *)savedbase, R, objlabel, objflag, saved_row);
@@ -1259,17 +1346,8 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
     hipLaunchKernelGGL(k_scan_sizes, dim3(1), dim3(1024), 0, st, (const unsigned long long *)sz, (const uint32_t *)(savedbase + n),
                        (long long *)ctx->crop_off.p, (long long *)ctx->bits_off.p, (long long *)ctx->band_off.p, totals);
     HIPCHK(hipGetLastError());
-    // per-frame tables and totals to the host; the label map is written while the host waits for them
-    uint32_t *h_ft = ctx->h_tmp.as<uint32_t>((size_t)n * 8 + 16);
-    HIPCHK(hipMemcpyAsync(h_ft, ftot3, ((size_t)3 * n + 2 * (n + 1)) * 4, hipMemcpyDeviceToHost, st));
-    std::vector<uint64_t> fs((size_t)n * 4);
-    uint64_t h_maskcnt = (uint64_t)P;
-    HIPCHK(hipMemcpyAsync(fs.data(), ctx->fsums.p, (size_t)n * 4 * 8, hipMemcpyDeviceToHost, st));
-    if (mask) HIPCHK(hipMemcpyAsync(&h_maskcnt, ctx->maskcnt.p, 8, hipMemcpyDeviceToHost, st));
-    std::vector<uint8_t> hvalid(n);
-    HIPCHK(hipMemcpyAsync(hvalid.data(), ctx->valid_dev.p, n, hipMemcpyDeviceToHost, st));
-    long long h_tot[4] = {0, 0, 0, 0};
-    HIPCHK(hipMemcpyAsync(h_tot, totals, 4 * 8, hipMemcpyDeviceToHost, st));
+    // per-frame tables and totals to the host (one copy of the head arena); the label map is written while the host waits
+    { int r_ = fetch_head(ctx); if (r_) return r_; }
     HIPCHK(hipEventRecord(ctx->ev[3], st));
     if (labels) {
         hipLaunchKernelGGL(k_label_fill, dim3(nblocks(P / 4), n), dim3(256), 0, st, S, (const int32_t *)objlabel, labels);
@@ -1277,18 +1355,28 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
     }
     HIPCHK(hipEventRecord(ctx->ev[4], st));
     HIPCHK(hipEventSynchronize(ctx->ev[3]));
-    const uint32_t *h_ftot3 = h_ft, *h_rowbase = h_ft + 3 * (size_t)n, *h_savedbase = h_rowbase + (n + 1);
+    ctx->head_on_host = true;
+    const HeadHost hh = head_host(ctx, n);
+    const uint32_t *h_ftot3 = hh.ftot3, *h_rowbase = hh.rowbase, *h_savedbase = hh.savedbase;
+    const long long *h_tot = hh.totals;
+    const uint64_t h_maskcnt = mask ? hh.maskcnt : (uint64_t)P;
     const int n_rows = (int)h_rowbase[n], n_saved = (int)h_savedbase[n];
+    // packed output arena: sums [n_saved][24] i64 | crop_off [n_saved+1] i64 | rows [10][n_rows] i32 | saved_row [n_saved] i32
+    const size_t hr = (size_t)(n_rows > 0 ? n_rows : 1), hs = (size_t)(n_saved > 0 ? n_saved : 1);
+    const size_t o_sums = 0, o_coff = o_sums + hs * PSEG_NSUMS * 8, o_rows = o_coff + (hs + 1) * 8, o_srow = o_rows + hr * 10 * 4;
+    const size_t o_bytes = o_srow + hs * 4;
+    ENSURE(ctx->outpack, o_bytes);
+    ENSURE_PIN(ctx->pin_tail, o_bytes);
+    long long *d_sums = (long long *)((char *)ctx->outpack.p + o_sums);
     if (n_saved > 0) {
         if (h_tot[2] > 0x7fffffffLL) return fail(ctx, PSEG_ERR_CAPACITY, "too many crop bands");
         ENSURE(ctx->crops_raw, (size_t)h_tot[0]); ENSURE(ctx->crops_masked, (size_t)h_tot[0]); ENSURE(ctx->crops_mask, (size_t)h_tot[0]);
-        ENSURE(ctx->sums, (size_t)n_saved * PSEG_NSUMS * 8);
         ENSURE(ctx->maskbits, (size_t)h_tot[1] * 2 * 4);     // first / last column of every window row (convex hull input)
-        hipLaunchKernelGGL(k_init_sums, dim3(nblocks((size_t)n_saved * PSEG_NSUMS)), dim3(256), 0, st, (long long *)ctx->sums.p, n_saved);
+        hipLaunchKernelGGL(k_init_sums, dim3(nblocks((size_t)n_saved * PSEG_NSUMS)), dim3(256), 0, st, d_sums, n_saved);
         hipLaunchKernelGGL(k_crops_sums, dim3((unsigned)h_tot[2]), dim3(256), 0, st, S, n_saved, (const int32_t *)geo,
                            (const long long *)ctx->crop_off.p, (const long long *)ctx->band_off.p, (const int32_t *)objflag,
                            cleaned, raw, (uint8_t *)ctx->crops_raw.p, (uint8_t *)ctx->crops_masked.p,
-                           (uint8_t *)ctx->crops_mask.p, (long long *)ctx->sums.p, (const long long *)ctx->bits_off.p,
+                           (uint8_t *)ctx->crops_mask.p, d_sums, (const long long *)ctx->bits_off.p,
                            (int32_t *)ctx->maskbits.p);
         const int hmax = (int)h_tot[3];
         const size_t hull_lds = (size_t)hmax * 16 + 16;
@@ -1296,27 +1384,25 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
         if (hull_lds > 48 * 1024)
             HIPCHK(hipFuncSetAttribute((const void *)k_convex, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hull_lds));
         hipLaunchKernelGGL(k_convex, dim3(n_saved), dim3(128), hull_lds, st, n_saved, (const int32_t *)geo,
-                           (const long long *)ctx->bits_off.p, (const int32_t *)ctx->maskbits.p, (long long *)ctx->sums.p, hmax);
+                           (const long long *)ctx->bits_off.p, (const int32_t *)ctx->maskbits.p, d_sums, hmax);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(ctx->ev[5], st));
     ctx->crop_bytes = h_tot[0];
     ctx->n_saved = n_saved;
 
-    // ---- results to the host ----
-    const size_t hr = (size_t)(n_rows > 0 ? n_rows : 1), hs = (size_t)(n_saved > 0 ? n_saved : 1);
-    int32_t *hrows = ctx->h_rows.as<int32_t>(hr * 10);
-    int32_t *h_saved_row = ctx->h_saved_row.as<int32_t>(hs);
-    int64_t *h_crop_off = ctx->h_crop_off.as<int64_t>(hs + 1);
-    int64_t *h_sums = ctx->h_sums.as<int64_t>(hs * PSEG_NSUMS);
+    // ---- results to the host: pack on the device, ONE copy into page-locked memory ----
+    char *hp = (char *)ctx->pin_tail.p;
+    int64_t *h_sums = (int64_t *)(hp + o_sums), *h_crop_off = (int64_t *)(hp + o_coff);
+    int32_t *hrows = (int32_t *)(hp + o_rows), *h_saved_row = (int32_t *)(hp + o_srow);
     h_crop_off[0] = 0;
-    if (n_rows > 0)
-        for (int k = 0; k < 10; k++)
-            HIPCHK(hipMemcpyAsync(hrows + k * hr, (int32_t *)ctx->rows.p + k * rcap, (size_t)n_rows * 4, hipMemcpyDeviceToHost, st));
-    if (n_saved > 0) {
-        HIPCHK(hipMemcpyAsync(h_saved_row, saved_row, (size_t)n_saved * 4, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipMemcpyAsync(h_crop_off, ctx->crop_off.p, (size_t)(n_saved + 1) * 8, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipMemcpyAsync(h_sums, ctx->sums.p, (size_t)n_saved * PSEG_NSUMS * 8, hipMemcpyDeviceToHost, st));
+    if (n_rows > 0) {
+        hipLaunchKernelGGL(k_pack_out, dim3(nblocks((size_t)n_rows + 1)), dim3(256), 0, st, (const int32_t *)ctx->rows.p, rcap, n_rows,
+                           (const int32_t *)saved_row, (const long long *)ctx->crop_off.p, n_saved,
+                           (int32_t *)((char *)ctx->outpack.p + o_rows), (int32_t *)((char *)ctx->outpack.p + o_srow),
+                           (long long *)((char *)ctx->outpack.p + o_coff));
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(hp, ctx->outpack.p, o_bytes, hipMemcpyDeviceToHost, st));
     }
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipEventElapsedTime(&ctx->ms[2], ctx->ev[2], ctx->ev[3]));
@@ -1331,8 +1417,8 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
     for (int f = 0; f <= n; f++) h_fro[f] = (int32_t)h_rowbase[f];
     for (int f = 0; f < n; f++) {
         h_fnc[f] = (int32_t)h_ftot3[3 * f];
-        h_fv[f] = hvalid[f];
-        finish_meanstd(fs.data() + 4 * f + 2, (double)h_maskcnt, &h_mean[f], &h_std[f]);
+        h_fv[f] = hh.valid[f];
+        finish_meanstd(hh.fsums + 4 * f + 2, (double)h_maskcnt, &h_mean[f], &h_std[f]);
     }
     double *h_area = ctx->h_area.as<double>(hr);
     uint8_t *h_s8 = ctx->h_saved8.as<uint8_t>(hr);
@@ -1414,8 +1500,7 @@ extern "C" int pseg_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t 
     unsigned nblk = nblocks(P / 8);
     ENSURE(ctx->bits, (size_t)n * P / 8);
     ENSURE(ctx->partials, (size_t)n * nblk * 4 * sizeof(uint32_t));
-    ENSURE(ctx->fsums, (size_t)n * 4 * sizeof(uint64_t));
-    ENSURE(ctx->valid_dev, (size_t)n);
+    { int r_ = head_setup(ctx, n); if (r_) return r_; }
     HIPCHK(hipEventRecord(ctx->ev[6], ctx->stream));
     if (valid) HIPCHK(hipMemcpyAsync(ctx->valid_dev.p, valid, n, hipMemcpyHostToDevice, ctx->stream));
     else HIPCHK(hipMemsetAsync(ctx->valid_dev.p, 1, n, ctx->stream));
@@ -1452,6 +1537,7 @@ extern "C" int pseg_process(pseg_ctx *ctx, const uint8_t *frames, int n, int n_b
     HIPCHK(hipEventRecord(ctx->ev[7], ctx->stream));
     r = fetch_raw_stats(ctx, n, mean_std, valid);
     if (r) return r;
+    HIPCHK(hipEventSynchronize(ctx->ev[7]));
     HIPCHK(hipEventElapsedTime(&ctx->ms[0], ctx->ev[0], ctx->ev[1]));
     HIPCHK(hipEventElapsedTime(&ctx->ms[5], ctx->ev[6], ctx->ev[7]));
     ctx->ms[1] = 0;
