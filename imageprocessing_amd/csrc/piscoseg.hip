@@ -62,11 +62,11 @@ struct pseg_ctx {
     bool head_on_host = false;    // pin_head holds this call's head (pseg_process reuses it for the raw statistics)
     // sparse workspaces
     DevBuf rowcnt, rowoff, framebase;
-    DevBuf run_x, run_fy, fg_parent, ext, bg_parent, bg_left, minx, maxx, maxy, area2, extrank,
+    DevBuf run_x, run_fy, fg_parent, ext, gapl, bg_parent, bg_left, minx, maxx, maxy, area2, extrank,
         keptrank, savedrank, objlabel, objflag;
     DevBuf rows, saved_row, saved_geo, crop_off, bits_off, maskbits, crops_raw, crops_masked, crops_mask;
     bool have_bits = false;       // threshold plane + masked sums already produced by the bg kernel
-    DevBuf bounds, band_off, trash;
+    DevBuf bounds, band_off, band_obj, trash;
     int bounds_n = -1, bounds_chunks = -1;
     int bg_chunks = 1;            // time chunks of the streaming background kernel (PSEG_BG_CHUNKS)
     bool force_generic = false;   // PSEG_BG_GENERIC=1: use the 12x-read reference kernel (debug / cross-check)
@@ -607,7 +607,10 @@ __global__ __launch_bounds__(256) void k_bbox(SegState S, int nfg)
         }
         atomicMin(&vminx[h], run_xs(S, r));
         atomicMax(&vmaxx[h], run_xe(S, r));
-        atomicMax(&vmaxy[h], (int)(S.run_fy[r] & 0xffffu));
+        const int y = (int)(S.run_fy[r] & 0xffffu), f = (int)(S.run_fy[r] >> 16);
+        atomicMax(&vmaxy[h], y);
+        // object that fills the gap on the left of this run (-1: none, or the row's leading gap)
+        S.gapl[r] = (r == seg_rowstart(S, f, y)) ? -1 : bg_gid(S, f, r + f * S.H + y);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 512; i += 256)
@@ -772,7 +775,7 @@ __global__ __launch_bounds__(256) void k_label_fill(SegState S, const int32_t *_
 
 // geometry of saved object s: geo[s*8] = f, x, y, w, h, root, words-per-row, row ; sz[s*3] = crop bytes,
 // mask words, row bands (a band = a run of rows of about CROP_BAND pixels: the unit of work of k_crops_sums)
-#define CROP_BAND 4096
+#define CROP_BAND 8192
 #define CROP_LDS_WORDS 1536          // mask words of a band + 2 halo rows on each side (frames up to 8192 px wide)
 __host__ __device__ inline int crop_rows_per_band(int w)
 {
@@ -827,6 +830,14 @@ __global__ __launch_bounds__(1024) void k_scan_sizes(const unsigned long long *s
     if (threadIdx.x < 3) { outp[threadIdx.x][n] = (long long)carry[threadIdx.x]; totals[threadIdx.x] = (long long)carry[threadIdx.x]; }
 }
 
+// band -> saved object (one wave per object), so that a band's block starts with one load instead of a binary search
+__global__ __launch_bounds__(256) void k_band_map(int n_saved, const long long *__restrict__ band_off, int32_t *__restrict__ band_obj)
+{
+    const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= n_saved) return;
+    for (long long b = band_off[s] + (threadIdx.x & 63); b < band_off[s + 1]; b += 64) band_obj[b] = s;
+}
+
 __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
@@ -846,29 +857,47 @@ __global__ __launch_bounds__(256) void k_crops_sums(SegState S, int n_saved, con
                                                     const int32_t *__restrict__ objflag, const uint8_t *__restrict__ cleaned,
                                                     const uint8_t *__restrict__ raw, uint8_t *__restrict__ c_raw,
                                                     uint8_t *__restrict__ c_masked, uint8_t *__restrict__ c_mask, long long *sums,
-                                                    const long long *__restrict__ row_off, int32_t *__restrict__ rowext)
+                                                    const long long *__restrict__ row_off, int32_t *__restrict__ rowext,
+                                                    const int32_t *__restrict__ band_obj)
 {
     __shared__ uint32_t mbuf[CROP_LDS_WORDS];             // mask bits of rows r0-2 .. r1+1 (zero outside the window)
     __shared__ uint32_t bd[CROP_LDS_WORDS];               // 4-neighbour border bits of rows r0-1 .. r1
-    int lo = 0, hi = n_saved;                             // object s with band_off[s] <= blockIdx.x < band_off[s+1]
     const long long bid = blockIdx.x;
-    while (hi - lo > 1) { int m = (lo + hi) >> 1; if (band_off[m] <= bid) lo = m; else hi = m; }
-    const int s = lo;
+    const int s = band_obj[bid];                          // band_off[s] <= blockIdx.x < band_off[s+1]
     const int32_t *o = geo + 8 * (size_t)s;
     const int f = o[0], bx = o[1], by = o[2], w = o[3], h = o[4], root = o[5], wpr = o[6];
     const int rpb = crop_rows_per_band(w);
     const int r0 = (int)(bid - band_off[s]) * rpb, r1 = (r0 + rpb < h) ? r0 + rpb : h;
     const int nrows = r1 - r0;
-    for (int wi = threadIdx.x; wi < (nrows + 4) * wpr; wi += 256) {
-        int yl = wi / wpr, wx = wi - yl * wpr;
-        int yy = r0 - 2 + yl;
-        uint32_t v = 0;
-        if (yy >= 0 && yy < h) {
-            int x0 = bx + 32 * wx, x1 = x0 + 31;
-            if (x1 > bx + w - 1) x1 = bx + w - 1;
-            v = mask_word_body(S, objflag, f, by + yy, x0, x1, root);
+    for (int wi = threadIdx.x; wi < (nrows + 4) * wpr; wi += 256) mbuf[wi] = 0;
+    __syncthreads();
+    {
+        // 16 threads per row walk the row's runs; a run paints itself and the gap on its left when the object that fills
+        // them (ext / gapl) is saved and was iterated at or before this one.  Two dependent global loads per row.
+        const int sub = threadIdx.x & 15, x_lo = bx, x_hi = bx + w - 1;
+        auto paint = [&](uint32_t *mrow, int xa, int xb) {
+            int la = (xa > x_lo ? xa : x_lo) - bx, lb = (xb < x_hi ? xb : x_hi) - bx;
+            for (int wd = la >> 5; wd <= (lb >> 5); wd++) {
+                int ba = la > 32 * wd ? la - 32 * wd : 0, bb = lb < 32 * wd + 31 ? lb - 32 * wd : 31;
+                uint32_t m = (bb - ba == 31) ? 0xffffffffu : (((1u << (bb - ba + 1)) - 1u) << ba);
+                atomicOr(&mrow[wd], m);
+            }
+        };
+        for (int yl = threadIdx.x >> 4; yl < nrows + 4; yl += 16) {
+            const int yy = r0 - 2 + yl;
+            if (yy < 0 || yy >= h) continue;
+            const int rs = seg_rowstart(S, f, by + yy), n = seg_rowcount(S, f, by + yy);
+            uint32_t *mrow = mbuf + yl * wpr;
+            for (int j = sub; j < n; j += 16) {
+                const int r = rs + j;
+                const uint32_t rx = S.run_x[r];
+                const int xs = (int)(rx & 0xffffu), xe = (int)(rx >> 16);
+                const int pe = j > 0 ? run_xe(S, r - 1) : x_hi;      // j == 0: the leading gap belongs to no object
+                const int idr = S.ext[r], idg = S.gapl[r];
+                if (xe >= x_lo && xs <= x_hi && idr >= root && (objflag[idr] & 2)) paint(mrow, xs, xe);
+                if (xs - 1 >= x_lo && pe + 1 <= x_hi && idg >= root && (objflag[idg] & 2)) paint(mrow, pe + 1, xs - 1);
+            }
         }
-        mbuf[wi] = v;
     }
     __syncthreads();
     // border = mask minus its erosion by the 4-neighbour cross, zero outside the window
@@ -887,27 +916,27 @@ __global__ __launch_bounds__(256) void k_crops_sums(SegState S, int n_saved, con
     const uint8_t *cl = cleaned + (size_t)f * P, *rw = raw + (size_t)f * P;
     const bool same = (raw == cleaned);                   // fused path: the Crops/ plane is cut from the same image
     const long long off = crop_off[s];
-    unsigned long long a[7] = {0, 0, 0, 0, 0, 0, 0};
-    uint32_t imin = 255, imax = 0;
+    unsigned long long a[6] = {0, 0, 0, 0, 0, 0};
+    uint32_t isum = 0, mn_e = 0x00ff00ffu, mn_o = 0x00ff00ffu, mx_e = 0, mx_o = 0;   // intensities: byte lanes as u16 pairs
     // thread = 4 consecutive pixels of a row: one (unaligned) 32-bit load / store per plane instead of four byte ones
     const int cpr = (w + 3) >> 2, nitem = (r1 - r0) * cpr;
     const float rcp = 1.0f / (float)cpr;
-#pragma unroll 2
+#pragma unroll 4
     for (int p = threadIdx.x; p < nitem; p += 256) {
         int yl = (int)((float)p * rcp);                   // p / cpr, corrected below (p < 2^24)
         int c = p - yl * cpr;
         if (c < 0) { yl--; c += cpr; } else if (c >= cpr) { yl++; c -= cpr; }
         const int yy = yl + r0, xx = 4 * c;
-        const uint32_t bits4 = (mb[yl * wpr + (xx >> 5)] >> (xx & 31)) & 0xfu;
+        const uint32_t bits4 = (mb[yl * wpr + (xx >> 5)] >> (xx & 31)) & 0xfu;   // bits beyond the row end are zero
         const uint8_t *src = cl + (size_t)(by + yy) * S.W + bx + xx;
         const uint8_t *srw = rw + (size_t)(by + yy) * S.W + bx + xx;
         const long long q = off + (long long)yy * w + xx;
+        const uint32_t m4 = ((bits4 * 0x00204081u) & 0x01010101u) * 255u;         // bit k -> byte k
         uint32_t cv4, rv4;
         const int nv = w - xx >= 4 ? 4 : w - xx;
         if (nv == 4) {
             __builtin_memcpy(&cv4, src, 4);
             if (same) rv4 = cv4; else __builtin_memcpy(&rv4, srw, 4);
-            uint32_t m4 = (bits4 & 1u ? 0xffu : 0u) | (bits4 & 2u ? 0xff00u : 0u) | (bits4 & 4u ? 0xff0000u : 0u) | (bits4 & 8u ? 0xff000000u : 0u);
             uint32_t cm4 = (cv4 & m4) | ~m4;                // where(mask, crop, 255)
             __builtin_memcpy(c_raw + q, &rv4, 4);
             __builtin_memcpy(c_mask + q, &m4, 4);
@@ -923,17 +952,37 @@ __global__ __launch_bounds__(256) void k_crops_sums(SegState S, int n_saved, con
                 c_masked[q + k] = bit ? cv : 255;
             }
         }
+        const uint32_t in4 = cv4 & m4, out4 = cv4 | ~m4;   // masked-out bytes: 0 for sum / max, 255 for min
+        isum = __builtin_amdgcn_sad_u8(in4, 0u, isum);
+        mx_e = pkmax(mx_e, __builtin_amdgcn_perm(0, in4, 0x0c020c00)); mx_o = pkmax(mx_o, __builtin_amdgcn_perm(0, in4, 0x0c030c01));
+        mn_e = pkmin(mn_e, __builtin_amdgcn_perm(0, out4, 0x0c020c00)); mn_o = pkmin(mn_o, __builtin_amdgcn_perm(0, out4, 0x0c030c01));
+    }
+    uint32_t imin, imax;
+    {
+        uint32_t mn = pkmin(mn_e, mn_o), mx = pkmax(mx_e, mx_o);
+        imin = (mn & 0xffffu) < (mn >> 16) ? (mn & 0xffffu) : (mn >> 16);
+        imax = (mx & 0xffffu) > (mx >> 16) ? (mx & 0xffffu) : (mx >> 16);
+    }
+    // geometric moments from the mask words: for a word with bit set S at columns X0 + k,
+    //   sum k = sum_b 2^b popc(S & M_b),  sum k^2 = sum_b 4^b popc(S & M_b) + 2 sum_{b<c} 2^(b+c) popc(S & M_b & M_c)
+    for (int wi = threadIdx.x; wi < nrows * wpr; wi += 256) {
+        const int yl = wi / wpr, wx = wi - yl * wpr;
+        const uint32_t v = mb[wi];
+        if (!v) continue;
+        const uint32_t M[5] = {0xaaaaaaaau, 0xccccccccu, 0xf0f0f0f0u, 0xff00ff00u, 0xffff0000u};
+        uint32_t n1 = (uint32_t)__popc(v), sk = 0, sk2 = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            if ((bits4 >> k) & 1u) {                      // bits beyond the row end are zero by construction of the mask words
-                const uint32_t cv = (cv4 >> (8 * k)) & 255u;
-                const int x = xx + k;
-                a[0] += 1; a[1] += yy; a[2] += x;
-                a[3] += (unsigned long long)yy * yy; a[4] += (unsigned long long)x * x; a[5] += (unsigned long long)yy * x;
-                a[6] += cv;
-                imin = cv < imin ? cv : imin; imax = cv > imax ? cv : imax;
-            }
+        for (int b2 = 0; b2 < 5; b2++) {
+            uint32_t pb = (uint32_t)__popc(v & M[b2]);
+            sk += pb << b2; sk2 += pb << (2 * b2);
+#pragma unroll
+            for (int c2 = b2 + 1; c2 < 5; c2++) sk2 += (uint32_t)__popc(v & M[b2] & M[c2]) << (b2 + c2 + 1);
         }
+        const uint32_t yy = (uint32_t)(r0 + yl), X0 = 32u * (uint32_t)wx;
+        const uint32_t sx = X0 * n1 + sk;                                          // < 2^19
+        const unsigned long long sx2 = (unsigned long long)X0 * X0 * n1 + 2ull * X0 * sk + sk2;
+        a[0] += n1; a[1] += (unsigned long long)yy * n1; a[2] += sx;
+        a[3] += (unsigned long long)yy * yy * n1; a[4] += sx2; a[5] += (unsigned long long)yy * sx;
     }
     // perimeter codes (skimage perimeter, _regionprops_utils.py:233-249): for a border pixel the 3x3 sum with
     // weights [[10,2,10],[2,1,2],[10,2,10]] over the border image is 1 + 2*n4 + 10*nd
@@ -978,7 +1027,8 @@ __global__ __launch_bounds__(256) void k_crops_sums(SegState S, int n_saved, con
         rowext[2 * (row_off[s] + r0 + yl)] = first;
         rowext[2 * (row_off[s] + r0 + yl) + 1] = last;
     }
-    for (int k = 0; k < 7; k++) a[k] = wave_sum_u64(a[k]);
+    for (int k = 0; k < 6; k++) a[k] = wave_sum_u64(a[k]);
+    const unsigned long long isum_w = wave_sum_u32(isum);
     for (int o2 = 32; o2 > 0; o2 >>= 1) {
         uint32_t t0 = __shfl_down(imin, o2, 64), t1 = __shfl_down(imax, o2, 64);
         imin = t0 < imin ? t0 : imin; imax = t1 > imax ? t1 : imax;
@@ -987,11 +1037,13 @@ __global__ __launch_bounds__(256) void k_crops_sums(SegState S, int n_saved, con
     eul = (int)wave_sum_u32((uint32_t)eul);
     if ((threadIdx.x & 63) == 0) {
         unsigned long long *q = (unsigned long long *)(sums + (size_t)s * PSEG_NSUMS);
-        if (a[0]) {
+        if (a[0]) {                                          // (the word loop and the pixel loop spread over the waves differently)
             atomicAdd(&q[0], a[0]); atomicAdd(&q[1], a[1]); atomicAdd(&q[2], a[2]); atomicAdd(&q[3], a[3]);
-            atomicAdd(&q[4], a[4]); atomicAdd(&q[5], a[5]); atomicAdd(&q[8], a[6]);
-            atomicMin((long long *)&q[6], (long long)imin); atomicMax((long long *)&q[7], (long long)imax);
+            atomicAdd(&q[4], a[4]); atomicAdd(&q[5], a[5]);
         }
+        if (isum_w) atomicAdd(&q[8], isum_w);
+        if (imin < 255) atomicMin((long long *)&q[6], (long long)imin);
+        if (imax > 0) atomicMax((long long *)&q[7], (long long)imax);
         if (pc1) atomicAdd(&q[10], (unsigned long long)pc1);
         if (pc2) atomicAdd(&q[11], (unsigned long long)pc2);
         if (pc3) atomicAdd(&q[12], (unsigned long long)pc3);
@@ -1116,11 +1168,11 @@ extern "C" int pseg_destroy(pseg_ctx *ctx)
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->bits, &ctx->partials, &ctx->head, &ctx->outpack, &ctx->rowspans, &ctx->rowcnt,
-                      &ctx->rowoff, &ctx->framebase, &ctx->run_x, &ctx->run_fy, &ctx->fg_parent, &ctx->ext,
+                      &ctx->rowoff, &ctx->framebase, &ctx->run_x, &ctx->run_fy, &ctx->fg_parent, &ctx->ext, &ctx->gapl,
                       &ctx->bg_parent, &ctx->bg_left, &ctx->minx, &ctx->maxx, &ctx->maxy, &ctx->area2,
                       &ctx->extrank, &ctx->keptrank, &ctx->savedrank, &ctx->objlabel, &ctx->objflag, &ctx->rows,
                       &ctx->saved_row, &ctx->saved_geo, &ctx->crop_off, &ctx->bits_off, &ctx->maskbits,
-                      &ctx->crops_raw, &ctx->crops_masked, &ctx->crops_mask, &ctx->bounds, &ctx->band_off, &ctx->trash};
+                      &ctx->crops_raw, &ctx->crops_masked, &ctx->crops_mask, &ctx->bounds, &ctx->band_off, &ctx->band_obj, &ctx->trash};
     for (DevBuf *b : bufs) if (b->p) hipFree(b->p);
     for (PinBuf *b : {&ctx->pin_head, &ctx->pin_tail, &ctx->pin_nfg}) if (b->p) hipHostFree(b->p);
     for (auto &e : ctx->ev) if (e) hipEventDestroy(e);
@@ -1292,13 +1344,13 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
     if (nfg_u > 0x3fffffffu) return fail(ctx, PSEG_ERR_CAPACITY, "too many foreground runs");
     const int nfg = (int)nfg_u, nbg = nfg + n * H;
     const size_t cap = (size_t)(nfg > 0 ? nfg : 1);
-    ENSURE(ctx->run_x, cap * 4); ENSURE(ctx->run_fy, cap * 4); ENSURE(ctx->fg_parent, cap * 4); ENSURE(ctx->ext, cap * 4);
+    ENSURE(ctx->run_x, cap * 4); ENSURE(ctx->run_fy, cap * 4); ENSURE(ctx->fg_parent, cap * 4); ENSURE(ctx->ext, cap * 4); ENSURE(ctx->gapl, cap * 4);
     ENSURE(ctx->bg_parent, (size_t)nbg * 4); ENSURE(ctx->bg_left, (size_t)nbg * 4);
     ENSURE(ctx->minx, cap * 4); ENSURE(ctx->maxx, cap * 4); ENSURE(ctx->maxy, cap * 4);
     ENSURE(ctx->area2, cap * 4); ENSURE(ctx->extrank, cap * 4); ENSURE(ctx->keptrank, cap * 4); ENSURE(ctx->savedrank, cap * 4);
     ENSURE(ctx->objlabel, cap * 4); ENSURE(ctx->objflag, cap * 4);
     S.run_x = (uint32_t *)ctx->run_x.p; S.run_fy = (uint32_t *)ctx->run_fy.p;
-    S.fg_parent = (int32_t *)ctx->fg_parent.p; S.ext = (int32_t *)ctx->ext.p;
+    S.fg_parent = (int32_t *)ctx->fg_parent.p; S.ext = (int32_t *)ctx->ext.p; S.gapl = (int32_t *)ctx->gapl.p;
     S.bg_parent = (int32_t *)ctx->bg_parent.p; S.bg_left = (int32_t *)ctx->bg_left.p;
     S.minx = (int32_t *)ctx->minx.p; S.maxx = (int32_t *)ctx->maxx.p; S.maxy = (int32_t *)ctx->maxy.p;
     S.area2 = (int32_t *)ctx->area2.p;
@@ -1372,12 +1424,15 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
         if (h_tot[2] > 0x7fffffffLL) return fail(ctx, PSEG_ERR_CAPACITY, "too many crop bands");
         ENSURE(ctx->crops_raw, (size_t)h_tot[0]); ENSURE(ctx->crops_masked, (size_t)h_tot[0]); ENSURE(ctx->crops_mask, (size_t)h_tot[0]);
         ENSURE(ctx->maskbits, (size_t)h_tot[1] * 2 * 4);     // first / last column of every window row (convex hull input)
+        ENSURE(ctx->band_obj, (size_t)h_tot[2] * 4);
+        hipLaunchKernelGGL(k_band_map, dim3(nblocks((size_t)n_saved, 4)), dim3(256), 0, st, n_saved, (const long long *)ctx->band_off.p,
+                           (int32_t *)ctx->band_obj.p);
         hipLaunchKernelGGL(k_init_sums, dim3(nblocks((size_t)n_saved * PSEG_NSUMS)), dim3(256), 0, st, d_sums, n_saved);
         hipLaunchKernelGGL(k_crops_sums, dim3((unsigned)h_tot[2]), dim3(256), 0, st, S, n_saved, (const int32_t *)geo,
                            (const long long *)ctx->crop_off.p, (const long long *)ctx->band_off.p, (const int32_t *)objflag,
                            cleaned, raw, (uint8_t *)ctx->crops_raw.p, (uint8_t *)ctx->crops_masked.p,
                            (uint8_t *)ctx->crops_mask.p, d_sums, (const long long *)ctx->bits_off.p,
-                           (int32_t *)ctx->maskbits.p);
+                           (int32_t *)ctx->maskbits.p, (const int32_t *)ctx->band_obj.p);
         const int hmax = (int)h_tot[3];
         const size_t hull_lds = (size_t)hmax * 16 + 16;
         if (hull_lds > 150 * 1024) return fail(ctx, PSEG_ERR_CAPACITY, "saved object too tall for the convex-hull kernel");

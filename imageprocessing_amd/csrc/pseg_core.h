@@ -53,6 +53,7 @@ struct SegState {
     uint32_t *run_fy;                // y | f << 16
     int32_t *fg_parent;              // union-find, root = smallest (raster-first) run
     int32_t *ext;                    // root run of the enclosing EXTERNAL component
+    int32_t *gapl;                   // external object whose filled region holds the gap left of the run, -1 = none
     // per background element (b = r + f*H + y for the gap left of run r; one extra per row)
     int32_t *bg_parent;
     int32_t *bg_left;                // foreground run immediately left of the gap, -1 for j = 0
@@ -214,7 +215,7 @@ PSEG_HD void span_begin(const SegState &S, SpanIter &it, int f, int y)
 PSEG_HD int span_elem_id(const SegState &S, const SpanIter &it, int e)
 {
     if (e & 1) return S.ext[it.rs + (e >> 1)];
-    return bg_gid(S, it.f, it.bb + (e >> 1));
+    return S.gapl[it.rs + (e >> 1)];                     // 0 < e < 2n: an inner gap
 }
 PSEG_HD bool span_next(const SegState &S, SpanIter &it, int &id, int &xs, int &xe)
 {
