@@ -862,6 +862,7 @@ __global__ __launch_bounds__(256) void k_crops_sums(SegState S, int n_saved, con
 {
     __shared__ uint32_t mbuf[CROP_LDS_WORDS];             // mask bits of rows r0-2 .. r1+1 (zero outside the window)
     __shared__ uint32_t bd[CROP_LDS_WORDS];               // 4-neighbour border bits of rows r0-1 .. r1
+    __shared__ uint32_t acc[32];                          // block totals (see the end of the kernel)
     const long long bid = blockIdx.x;
     const int s = band_obj[bid];                          // band_off[s] <= blockIdx.x < band_off[s+1]
     const int32_t *o = geo + 8 * (size_t)s;
@@ -870,6 +871,7 @@ __global__ __launch_bounds__(256) void k_crops_sums(SegState S, int n_saved, con
     const int r0 = (int)(bid - band_off[s]) * rpb, r1 = (r0 + rpb < h) ? r0 + rpb : h;
     const int nrows = r1 - r0;
     for (int wi = threadIdx.x; wi < (nrows + 4) * wpr; wi += 256) mbuf[wi] = 0;
+    if (threadIdx.x < 32) acc[threadIdx.x] = threadIdx.x == 15 ? 255u : 0u;    // acc[15] = running minimum
     __syncthreads();
     {
         // 16 threads per row walk the row's runs; a run paints itself and the gap on its left when the object that fills
@@ -913,49 +915,54 @@ __global__ __launch_bounds__(256) void k_crops_sums(SegState S, int n_saved, con
     __syncthreads();
     const uint32_t *mb = mbuf + 2 * wpr;                  // row r0 of the band
     const size_t P = (size_t)S.H * S.W;
-    const uint8_t *cl = cleaned + (size_t)f * P, *rw = raw + (size_t)f * P;
     const bool same = (raw == cleaned);                   // fused path: the Crops/ plane is cut from the same image
-    const long long off = crop_off[s];
-    unsigned long long a[6] = {0, 0, 0, 0, 0, 0};
+    // block-uniform bases; per-item offsets stay 32-bit
+    const uint8_t *sb = cleaned + (size_t)f * P + (size_t)(by + r0) * S.W + bx;
+    const uint8_t *rb = raw + (size_t)f * P + (size_t)(by + r0) * S.W + bx;
+    const long long off = crop_off[s] + (long long)r0 * w;
+    uint8_t *o_raw = c_raw + off, *o_mask = c_mask + off, *o_masked = c_masked + off;
     uint32_t isum = 0, mn_e = 0x00ff00ffu, mn_o = 0x00ff00ffu, mx_e = 0, mx_o = 0;   // intensities: byte lanes as u16 pairs
-    // thread = 4 consecutive pixels of a row: one (unaligned) 32-bit load / store per plane instead of four byte ones
-    const int cpr = (w + 3) >> 2, nitem = (r1 - r0) * cpr;
-    const float rcp = 1.0f / (float)cpr;
+    if (w >= 4) {
+        // thread = 4 consecutive pixels of a row: one (unaligned) 32-bit load / store per plane.  The last chunk of a row is
+        // shifted back to end at the row end (it rewrites bytes of its neighbour with the same values); `keep` drops the
+        // bytes it shares with the neighbour from the sums.
+        const int cpr = (w + 3) >> 2, nitem = nrows * cpr;
+        const float rcp = 1.0f / (float)cpr;
 #pragma unroll 4
-    for (int p = threadIdx.x; p < nitem; p += 256) {
-        int yl = (int)((float)p * rcp);                   // p / cpr, corrected below (p < 2^24)
-        int c = p - yl * cpr;
-        if (c < 0) { yl--; c += cpr; } else if (c >= cpr) { yl++; c -= cpr; }
-        const int yy = yl + r0, xx = 4 * c;
-        const uint32_t bits4 = (mb[yl * wpr + (xx >> 5)] >> (xx & 31)) & 0xfu;   // bits beyond the row end are zero
-        const uint8_t *src = cl + (size_t)(by + yy) * S.W + bx + xx;
-        const uint8_t *srw = rw + (size_t)(by + yy) * S.W + bx + xx;
-        const long long q = off + (long long)yy * w + xx;
-        const uint32_t m4 = ((bits4 * 0x00204081u) & 0x01010101u) * 255u;         // bit k -> byte k
-        uint32_t cv4, rv4;
-        const int nv = w - xx >= 4 ? 4 : w - xx;
-        if (nv == 4) {
-            __builtin_memcpy(&cv4, src, 4);
-            if (same) rv4 = cv4; else __builtin_memcpy(&rv4, srw, 4);
-            uint32_t cm4 = (cv4 & m4) | ~m4;                // where(mask, crop, 255)
-            __builtin_memcpy(c_raw + q, &rv4, 4);
-            __builtin_memcpy(c_mask + q, &m4, 4);
-            __builtin_memcpy(c_masked + q, &cm4, 4);
-        } else {
-            cv4 = 0;
-            for (int k = 0; k < nv; k++) {
-                uint8_t cv = src[k];
-                bool bit = (bits4 >> k) & 1u;
-                cv4 |= (uint32_t)cv << (8 * k);
-                c_raw[q + k] = same ? cv : srw[k];
-                c_mask[q + k] = bit ? 255 : 0;
-                c_masked[q + k] = bit ? cv : 255;
-            }
+        for (int p = threadIdx.x; p < nitem; p += 256) {
+            int yl = (int)((float)p * rcp);               // p / cpr, corrected below (p < 2^24)
+            int c = p - yl * cpr;
+            if (c < 0) { yl--; c += cpr; } else if (c >= cpr) { yl++; c -= cpr; }
+            int xx = 4 * c;
+            const int over = xx - (w - 4);                // > 0 only for the last chunk of a row when w % 4 != 0
+            uint32_t keep = 0xffffffffu;
+            if (over > 0) { xx = w - 4; keep <<= 8 * over; }
+            const uint32_t *mw = mb + yl * wpr + (xx >> 5);
+            const uint32_t bits4 = __builtin_amdgcn_alignbit(mw[1], mw[0], (uint32_t)(xx & 31)) & 0xfu;
+            const uint32_t so = (uint32_t)yl * (uint32_t)S.W + (uint32_t)xx, qo = (uint32_t)yl * (uint32_t)w + (uint32_t)xx;
+            const uint32_t m4 = ((bits4 * 0x00204081u) & 0x01010101u) * 255u;     // bit k -> byte k
+            uint32_t cv4, rv4;
+            __builtin_memcpy(&cv4, sb + so, 4);
+            if (same) rv4 = cv4; else __builtin_memcpy(&rv4, rb + so, 4);
+            const uint32_t cm4 = (cv4 & m4) | ~m4;        // where(mask, crop, 255)
+            __builtin_memcpy(o_raw + qo, &rv4, 4);
+            __builtin_memcpy(o_mask + qo, &m4, 4);
+            __builtin_memcpy(o_masked + qo, &cm4, 4);
+            const uint32_t mk = m4 & keep, in4 = cv4 & mk, out4 = cv4 | ~mk;   // masked-out bytes: 0 for sum / max, 255 for min
+            isum = __builtin_amdgcn_sad_u8(in4, 0u, isum);
+            mx_e = pkmax(mx_e, __builtin_amdgcn_perm(0, in4, 0x0c020c00)); mx_o = pkmax(mx_o, __builtin_amdgcn_perm(0, in4, 0x0c030c01));
+            mn_e = pkmin(mn_e, __builtin_amdgcn_perm(0, out4, 0x0c020c00)); mn_o = pkmin(mn_o, __builtin_amdgcn_perm(0, out4, 0x0c030c01));
         }
-        const uint32_t in4 = cv4 & m4, out4 = cv4 | ~m4;   // masked-out bytes: 0 for sum / max, 255 for min
-        isum = __builtin_amdgcn_sad_u8(in4, 0u, isum);
-        mx_e = pkmax(mx_e, __builtin_amdgcn_perm(0, in4, 0x0c020c00)); mx_o = pkmax(mx_o, __builtin_amdgcn_perm(0, in4, 0x0c030c01));
-        mn_e = pkmin(mn_e, __builtin_amdgcn_perm(0, out4, 0x0c020c00)); mn_o = pkmin(mn_o, __builtin_amdgcn_perm(0, out4, 0x0c030c01));
+    } else {                                              // windows narrower than a dword: thread per pixel
+        for (int p = threadIdx.x; p < nrows * w; p += 256) {
+            const int yl = p / w, xx = p - yl * w;
+            const uint32_t bit = (mb[yl * wpr] >> xx) & 1u;
+            const uint32_t cv = sb[(size_t)yl * S.W + xx];
+            o_raw[p] = same ? (uint8_t)cv : rb[(size_t)yl * S.W + xx];
+            o_mask[p] = bit ? 255 : 0;
+            o_masked[p] = bit ? (uint8_t)cv : 255;
+            if (bit) { isum += cv; mx_e = pkmax(mx_e, cv); mn_e = pkmin(mn_e, cv | 0x00ff0000u); }
+        }
     }
     uint32_t imin, imax;
     {
@@ -963,46 +970,52 @@ __global__ __launch_bounds__(256) void k_crops_sums(SegState S, int n_saved, con
         imin = (mn & 0xffffu) < (mn >> 16) ? (mn & 0xffffu) : (mn >> 16);
         imax = (mx & 0xffffu) > (mx >> 16) ? (mx & 0xffffu) : (mx >> 16);
     }
-    // geometric moments from the mask words: for a word with bit set S at columns X0 + k,
-    //   sum k = sum_b 2^b popc(S & M_b),  sum k^2 = sum_b 4^b popc(S & M_b) + 2 sum_{b<c} 2^(b+c) popc(S & M_b & M_c)
-    for (int wi = threadIdx.x; wi < nrows * wpr; wi += 256) {
-        const int yl = wi / wpr, wx = wi - yl * wpr;
-        const uint32_t v = mb[wi];
-        if (!v) continue;
-        const uint32_t M[5] = {0xaaaaaaaau, 0xccccccccu, 0xf0f0f0f0u, 0xff00ff00u, 0xffff0000u};
-        uint32_t n1 = (uint32_t)__popc(v), sk = 0, sk2 = 0;
-#pragma unroll
-        for (int b2 = 0; b2 < 5; b2++) {
-            uint32_t pb = (uint32_t)__popc(v & M[b2]);
-            sk += pb << b2; sk2 += pb << (2 * b2);
-#pragma unroll
-            for (int c2 = b2 + 1; c2 < 5; c2++) sk2 += (uint32_t)__popc(v & M[b2] & M[c2]) << (b2 + c2 + 1);
-        }
-        const uint32_t yy = (uint32_t)(r0 + yl), X0 = 32u * (uint32_t)wx;
-        const uint32_t sx = X0 * n1 + sk;                                          // < 2^19
-        const unsigned long long sx2 = (unsigned long long)X0 * X0 * n1 + 2ull * X0 * sk + sk2;
-        a[0] += n1; a[1] += (unsigned long long)yy * n1; a[2] += sx;
-        a[3] += (unsigned long long)yy * yy * n1; a[4] += sx2; a[5] += (unsigned long long)yy * sx;
-    }
-    // perimeter codes (skimage perimeter, _regionprops_utils.py:233-249): for a border pixel the 3x3 sum with
-    // weights [[10,2,10],[2,1,2],[10,2,10]] over the border image is 1 + 2*n4 + 10*nd
+    // One pass over the band's words: geometric moments and perimeter codes, both bit-parallel.
+    //  moments: for a word with bits at columns 32*wx + k,  sum k = sum_b 2^b popc(v & M_b),
+    //           sum k^2 = sum_b 4^b popc(v & M_b) + 2 sum_{b<c} 2^(b+c) popc(v & M_b & M_c); rows are band-local (yl), the
+    //           band offset r0 is folded in once per block, so every partial sum of the block fits 32 bits
+    //  perimeter codes (skimage perimeter, _regionprops_utils.py:233-249): for a border pixel the 3x3 sum with weights
+    //           [[10,2,10],[2,1,2],[10,2,10]] over the border image is 1 + 2*n4 + 10*nd; n4 / nd are counted with bit-sliced adders
+    uint32_t mo[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // n, wx n, wx^2 n, sk, wx sk, sk2, yl n, yl^2 n, yl wx n, yl sk
     uint32_t pc1 = 0, pc2 = 0, pc3 = 0;
     for (int wi = threadIdx.x; wi < nrows * wpr; wi += 256) {
-        int yl = wi / wpr, wx = wi - yl * wpr;
-        const uint32_t *bc = bd + (yl + 1) * wpr;          // border row r0+yl
-        uint32_t v = bc[wx];
-        while (v) {
-            int k = __ffs(v) - 1;
-            v &= v - 1;
-            int x = 32 * wx + k;
-            auto bit = [&](const uint32_t *row, int xx) -> int {
-                return (xx >= 0 && xx < 32 * wpr) ? (int)((row[xx >> 5] >> (xx & 31)) & 1u) : 0;
+        const uint32_t yl = (uint32_t)(wi / wpr), wx = (uint32_t)wi - yl * (uint32_t)wpr;
+        const uint32_t v = mb[wi];
+        if (v) {
+            const uint32_t M[5] = {0xaaaaaaaau, 0xccccccccu, 0xf0f0f0f0u, 0xff00ff00u, 0xffff0000u};
+            uint32_t n1 = (uint32_t)__popc(v), sk = 0, sk2 = 0;
+#pragma unroll
+            for (int b2 = 0; b2 < 5; b2++) {
+                uint32_t pb = (uint32_t)__popc(v & M[b2]);
+                sk += pb << b2; sk2 += pb << (2 * b2);
+#pragma unroll
+                for (int c2 = b2 + 1; c2 < 5; c2++) sk2 += (uint32_t)__popc(v & M[b2] & M[c2]) << (b2 + c2 + 1);
+            }
+            mo[0] += n1; mo[1] += wx * n1; mo[2] += wx * wx * n1; mo[3] += sk; mo[4] += wx * sk; mo[5] += sk2;
+            mo[6] += yl * n1; mo[7] += yl * yl * n1; mo[8] += yl * wx * n1; mo[9] += yl * sk;
+        }
+        const uint32_t *bc = bd + (yl + 1) * wpr + wx;     // border row r0+yl
+        const uint32_t C = bc[0];
+        if (C) {
+            const bool hl = wx > 0, hr = wx + 1 < (uint32_t)wpr;
+            const uint32_t U = bc[-wpr], D = bc[wpr];
+            const uint32_t cl1 = hl ? bc[-1] >> 31 : 0u, cr1 = hr ? bc[1] << 31 : 0u;
+            const uint32_t ul1 = hl ? bc[-wpr - 1] >> 31 : 0u, ur1 = hr ? bc[-wpr + 1] << 31 : 0u;
+            const uint32_t dl1 = hl ? bc[wpr - 1] >> 31 : 0u, dr1 = hr ? bc[wpr + 1] << 31 : 0u;
+            const uint32_t L = (C << 1) | cl1, R = (C >> 1) | cr1;
+            const uint32_t UL = (U << 1) | ul1, UR = (U >> 1) | ur1, DL = (D << 1) | dl1, DR = (D >> 1) | dr1;
+            // a + b + c + d per bit position -> three bit planes
+            auto add4 = [](uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t &s0, uint32_t &s1, uint32_t &s2) {
+                uint32_t h1 = a ^ b, c1 = a & b, h2 = c ^ d, c2 = c & d, t = h1 & h2;
+                s0 = h1 ^ h2; s1 = c1 ^ c2 ^ t; s2 = c1 & c2;
             };
-            int n4 = bit(bc, x - 1) + bit(bc, x + 1) + bit(bc - wpr, x) + bit(bc + wpr, x);
-            int nd = bit(bc - wpr, x - 1) + bit(bc - wpr, x + 1) + bit(bc + wpr, x - 1) + bit(bc + wpr, x + 1);
-            if ((n4 == 2 || n4 == 3) && nd <= 2) pc1++;                       // codes 5,7,15,17,25,27 -> 1
-            else if ((n4 == 0 && nd == 2) || (n4 == 1 && nd == 3)) pc2++;      // codes 21,33 -> sqrt(2)
-            else if (n4 == 1 && (nd == 1 || nd == 2)) pc3++;                   // codes 13,23 -> (1+sqrt(2))/2
+            uint32_t a0, a1, a2, d0, d1, d2;
+            add4(L, R, U, D, a0, a1, a2);
+            add4(UL, UR, DL, DR, d0, d1, d2);
+            const uint32_t n4_1 = a0 & ~a1 & ~a2, n4_0 = ~(a0 | a1 | a2);
+            pc1 += (uint32_t)__popc(C & a1 & ~(d2 | (d1 & d0)));                       // n4 in {2,3}, nd <= 2: codes 5,7,15,17,25,27 -> 1
+            pc2 += (uint32_t)__popc(C & ((n4_0 & ~d0 & d1) | (n4_1 & d0 & d1)));       // codes 21,33 -> sqrt(2)
+            pc3 += (uint32_t)__popc(C & n4_1 & (d0 ^ d1) & ~d2);                       // codes 13,23 -> (1+sqrt(2))/2
         }
     }
     // Euler number, 8-connectivity (skimage euler_number, _regionprops_utils.py:140-181): 2x2 quads of the
@@ -1027,27 +1040,44 @@ __global__ __launch_bounds__(256) void k_crops_sums(SegState S, int n_saved, con
         rowext[2 * (row_off[s] + r0 + yl)] = first;
         rowext[2 * (row_off[s] + r0 + yl) + 1] = last;
     }
-    for (int k = 0; k < 6; k++) a[k] = wave_sum_u64(a[k]);
-    const unsigned long long isum_w = wave_sum_u32(isum);
+    // block totals: DPP wave sums (every partial fits 32 bits, see above), lane 63 adds them into LDS, one thread flushes
+    // with 64-bit integer atomics (exact, order-independent)
+#pragma unroll
+    for (int k = 0; k < 10; k++) mo[k] = wave_sum63(mo[k]);
+    isum = wave_sum63(isum); pc1 = wave_sum63(pc1); pc2 = wave_sum63(pc2); pc3 = wave_sum63(pc3);
+    const uint32_t eulw = wave_sum63((uint32_t)eul);
     for (int o2 = 32; o2 > 0; o2 >>= 1) {
-        uint32_t t0 = __shfl_down(imin, o2, 64), t1 = __shfl_down(imax, o2, 64);
+        uint32_t t0 = __shfl_xor(imin, o2, 64), t1 = __shfl_xor(imax, o2, 64);
         imin = t0 < imin ? t0 : imin; imax = t1 > imax ? t1 : imax;
     }
-    pc1 = wave_sum_u32(pc1); pc2 = wave_sum_u32(pc2); pc3 = wave_sum_u32(pc3);
-    eul = (int)wave_sum_u32((uint32_t)eul);
-    if ((threadIdx.x & 63) == 0) {
+    if ((threadIdx.x & 63) == 63) {
+#pragma unroll
+        for (int k = 0; k < 10; k++) if (mo[k]) atomicAdd(&acc[k], mo[k]);
+        if (isum) atomicAdd(&acc[10], isum);
+        if (pc1) atomicAdd(&acc[11], pc1);
+        if (pc2) atomicAdd(&acc[12], pc2);
+        if (pc3) atomicAdd(&acc[13], pc3);
+        if (eulw) atomicAdd(&acc[14], eulw);
+        atomicMin(&acc[15], imin); atomicMax(&acc[16], imax);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
         unsigned long long *q = (unsigned long long *)(sums + (size_t)s * PSEG_NSUMS);
-        if (a[0]) {                                          // (the word loop and the pixel loop spread over the waves differently)
-            atomicAdd(&q[0], a[0]); atomicAdd(&q[1], a[1]); atomicAdd(&q[2], a[2]); atomicAdd(&q[3], a[3]);
-            atomicAdd(&q[4], a[4]); atomicAdd(&q[5], a[5]);
+        const unsigned long long N = acc[0], R0 = (unsigned long long)r0;
+        if (N) {
+            const unsigned long long sx = 32ull * acc[1] + acc[3];                                    // sum c
+            const unsigned long long sx2 = 1024ull * acc[2] + 64ull * acc[4] + acc[5];                // sum c^2
+            const unsigned long long sy = acc[6], sy2 = acc[7], syx = 32ull * acc[8] + acc[9];        // band-local rows
+            atomicAdd(&q[0], N); atomicAdd(&q[1], R0 * N + sy); atomicAdd(&q[2], sx);
+            atomicAdd(&q[3], R0 * R0 * N + 2ull * R0 * sy + sy2); atomicAdd(&q[4], sx2); atomicAdd(&q[5], R0 * sx + syx);
         }
-        if (isum_w) atomicAdd(&q[8], isum_w);
-        if (imin < 255) atomicMin((long long *)&q[6], (long long)imin);
-        if (imax > 0) atomicMax((long long *)&q[7], (long long)imax);
-        if (pc1) atomicAdd(&q[10], (unsigned long long)pc1);
-        if (pc2) atomicAdd(&q[11], (unsigned long long)pc2);
-        if (pc3) atomicAdd(&q[12], (unsigned long long)pc3);
-        if (eul) atomicAdd(&q[13], (unsigned long long)(long long)eul);
+        if (acc[10]) atomicAdd(&q[8], (unsigned long long)acc[10]);
+        if (acc[15] < 255u) atomicMin((long long *)&q[6], (long long)acc[15]);
+        if (acc[16] > 0u) atomicMax((long long *)&q[7], (long long)acc[16]);
+        if (acc[11]) atomicAdd(&q[10], (unsigned long long)acc[11]);
+        if (acc[12]) atomicAdd(&q[11], (unsigned long long)acc[12]);
+        if (acc[13]) atomicAdd(&q[12], (unsigned long long)acc[13]);
+        if (acc[14]) atomicAdd(&q[13], (unsigned long long)(long long)(int)acc[14]);
     }
 }
 
