@@ -121,3 +121,46 @@ def test_bg_stream_kernel_vs_oracle(monkeypatch, n, chunks):
             thr = ((255 - it[1]) > 100) & (mask == 255)
             assert tab.frame_n_contours[i] == len(helpers.cv_ref.findContours(thr.astype(np.uint8), 0, 2)[0])
     seg.close()
+
+
+def test_detect_edge_cases(gpu_seg_factory):
+    """Hand-made frames: empty frame, nothing saved, areas exactly on both thresholds, windows narrower than a
+    dword (w = 2, 3), widths with every w % 4, objects on all four frame edges, a full-width object, nested rings."""
+    import torch
+    H, W = 128, 192
+    seg = gpu_seg_factory(H, W)
+    rng = np.random.default_rng(11)
+    fr = []
+
+    def blank():
+        return np.full((H, W), 255, np.uint8)
+
+    def put(img, y, x, h, w):
+        img[y:y + h, x:x + w] = rng.integers(0, 200, (h, w), dtype=np.uint8)
+
+    fr.append(blank())                                             # 0: empty
+    a = blank(); put(a, 5, 5, 2, 11); put(a, 20, 20, 6, 3); put(a, 40, 40, 3, 3); fr.append(a)   # 1: areas 10, 10, 4: nothing saved
+    a = blank(); put(a, 10, 10, 21, 21); put(a, 50, 10, 21, 22); put(a, 10, 60, 22, 21); fr.append(a)   # 2: area 400 (not saved), 420, 420
+    a = blank(); put(a, 4, 7, 100, 2); put(a, 10, 30, 90, 3); put(a, 3, 50, 120, 1); fr.append(a)      # 3: w = 2, 3, 1
+    a = blank()
+    for k, w in enumerate([5, 6, 7, 8, 9, 33, 34, 63]):
+        put(a, 2 + 15 * (k % 8), 3 + (k // 8) * 70, 12, w)
+    fr.append(a)                                                   # 4: widths with every remainder mod 4 / word straddles
+    a = blank(); put(a, 0, 0, 12, 14); put(a, 0, W - 9, 30, 9); put(a, H - 7, 40, 7, 50); put(a, 50, 0, 40, 6); fr.append(a)   # 5: edges
+    a = blank(); put(a, 30, 0, 9, W); fr.append(a)                 # 6: full width
+    a = blank(); put(a, 0, 0, H, W); a[1:-1, 1:-1] = 255; put(a, 10, 10, 60, 60); a[14:66, 14:66] = 255; put(a, 30, 30, 10, 10)
+    fr.append(a)                                                   # 7: frame-sized ring > ring > blob
+    cleaned = np.stack(fr)
+    n = cleaned.shape[0]
+    items = [(cleaned[f], cleaned[f], [100.0, 50.0], f"e_{f:03d}.png") for f in range(n)]
+    for min_save in (400, 20):
+        dets = helpers.oracle_detect(items, None, min_area_to_segment=10, min_area_to_save=min_save, mask_img=False)
+        labels = torch.empty((n, H, W), dtype=torch.int32, device="cuda")
+        tab = seg.detect(torch.from_numpy(cleaned).cuda(), min_area_to_segment=10, min_area_to_save=min_save, labels=labels,
+                         fetch_crops=True)
+        helpers.compare_table(tab, dets, H, W, labels=labels.cpu().numpy())
+        assert tab.frame_row_offset[1] == 0 and tab.frame_n_contours[0] == 0
+    # a batch in which no frame has any object at all
+    empty = np.full((3, H, W), 255, np.uint8)
+    tab = seg.detect(torch.from_numpy(empty).cuda(), fetch_crops=True)
+    assert tab.n_rows == 0 and tab.crop_bytes == 0 and len(tab.saved_row) == 0
