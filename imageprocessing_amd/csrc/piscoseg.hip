@@ -1083,79 +1083,85 @@ __global__ __launch_bounds__(256) void k_crops_sums(SegState S, int n_saved, con
 
 // Convex hull area (skimage convex_hull_image, morphology/convex_hull.py:73-145): hull of the +-0.5 "diamond"
 // points of the row-extremal pixels, then every pixel centre inside or on the hull.  In doubled coordinates
-// R = 2*row (+-1), X = 2*col (+-1) the hull's left chain is the lower convex envelope of L(R) and the right chain
-// the upper envelope of U(R); both are built by one lane with a monotone-chain stack in LDS (exact integers),
-// then the lanes count the pixel centres row by row.  Block of 64 threads per saved object.
-// Each chain is found by a wave-parallel gift-wrapping march: from the current vertex a, the next vertex is the
-// point of extreme slope among all later points (64 lanes scan + a wave reduction, exact 64-bit cross products;
-// ties go to the farthest point).  The rows spanned by the new hull edge get their column bound right away, so no
-// vertex list is stored.  Wave 0 walks the left chain, wave 1 the right chain.  Dynamic LDS: 16 bytes per row
-// (first / last column, left / right bound), sized by the tallest saved object of the batch.
+// R' = 2*row + 1 (+-1), X = 2*col (+-1) the hull's left chain is the lower convex envelope of the profile L(R') and
+// the right chain the upper envelope of U(R'):  odd R' = pixel row r (points (2r, 2c -+ 1)), even R' = between rows
+// r-1 and r ((2r-1, 2c) of either row).  Wave 0 walks the left chain, wave 1 the right chain by a wave-parallel
+// gift-wrapping march: from vertex a, the next vertex is the point of extreme slope among all later points (64 lanes
+// scan + a wave reduction; exact 32-bit cross products: |dX| < 2^15, |dR'| < 2^14 for the heights the LDS admits; ties
+// go to the farthest point).  The vertex list goes to LDS; afterwards every pixel row finds its hull edge by binary
+// search and gets its column bound with one division.  Dynamic LDS: 40 bytes per row of the tallest object served
+// by the launch (the host launches one size class per call so that small objects keep a high occupancy).
+#define HULL_LDS_PER_ROW 40
 template <bool LOWER>
-__device__ __forceinline__ void hull_march(const int *fl, int h, int *bound, int lane)
+__device__ __forceinline__ void hull_chain(const int *pv, int np, int *vl, int *bound, int h, int lane)
 {
-    const int np = 2 * h + 1;
-    // profile over R' = R + 1: odd R' = pixel row r (points (2r, 2c -+ 1)), even R' = between rows r-1 and r ((2r-1, 2c))
-    auto prof = [&](int i) -> int {
-        const int r = i >> 1, k = LOWER ? 0 : 1;
-        if (i & 1) return LOWER ? 2 * fl[2 * r] - 1 : 2 * fl[2 * r + 1] + 1;
-        int va = r - 1 >= 0 ? 2 * fl[2 * (r - 1) + k] : (LOWER ? 0x3fffffff : -0x3fffffff);
-        int vb = r < h ? 2 * fl[2 * r + k] : (LOWER ? 0x3fffffff : -0x3fffffff);
-        return LOWER ? (va < vb ? va : vb) : (va > vb ? va : vb);
-    };
-    int a = 0, va = prof(0);
+    int a = 0, va = pv[0], nv = 1;
+    if (lane == 0) vl[0] = 0;
     while (a < np - 1) {
         int bj = -1, bv = 0;
         for (int j = a + 1 + lane; j < np; j += 64) {
-            int v = prof(j);
-            if (bj < 0) { bj = j; bv = v; }
-            else {
-                long long d = (long long)(v - va) * (bj - a) - (long long)(bv - va) * (j - a);
-                if (LOWER ? d <= 0 : d >= 0) { bj = j; bv = v; }      // j > bj: a tie goes to the farther point
-            }
+            const int v = pv[j];
+            const int d = (v - va) * (bj - a) - (bv - va) * (j - a);
+            if (bj < 0 || (LOWER ? d <= 0 : d >= 0)) { bj = j; bv = v; }      // j > bj: a tie goes to the farther point
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
-            int oj = __shfl_xor(bj, o, 64), ov = __shfl_xor(bv, o, 64);
-            if (oj >= 0) {
-                bool take = bj < 0;
-                if (!take) {
-                    long long d = (long long)(ov - va) * (bj - a) - (long long)(bv - va) * (oj - a);
-                    take = LOWER ? (d < 0 || (d == 0 && oj > bj)) : (d > 0 || (d == 0 && oj > bj));
-                }
-                if (take) { bj = oj; bv = ov; }
-            }
+            const int oj = __shfl_xor(bj, o, 64), ov = __shfl_xor(bv, o, 64);
+            const int d = (ov - va) * (bj - a) - (bv - va) * (oj - a);
+            const bool better = LOWER ? (d < 0 || (d == 0 && oj > bj)) : (d > 0 || (d == 0 && oj > bj));
+            if (oj >= 0 && (bj < 0 || better)) { bj = oj; bv = ov; }
         }
-        const int b = bj, vb = bv;                          // the same in every lane
-        const long long den = b - a, twoden = 2 * den;
-        for (int i = (a | 1) + 2 * lane; i <= b; i += 128) {  // pixel rows (odd R') on the new edge (a, b]
-            if (i <= a) continue;
-            long long num = (long long)va * den + (long long)(vb - va) * (i - a);
-            long long c = LOWER ? (num >= 0 ? (num + twoden - 1) / twoden : -((-num) / twoden))     // ceil(num / (2 den))
-                                : (num >= 0 ? num / twoden : -((-num + twoden - 1) / twoden));      // floor(num / (2 den))
-            bound[i >> 1] = (int)c;
-        }
-        a = b; va = vb;
+        a = bj; va = bv;                                    // the same in every lane
+        if (lane == 0) vl[nv] = a;
+        nv++;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int r = lane; r < h; r += 64) {                    // pixel row r = profile index 2r+1
+        const int i = 2 * r + 1;
+        int lo = 0, hi = nv - 1;                            // edge k with vl[k] < i <= vl[k+1]
+        while (hi - lo > 1) { const int m = (lo + hi) >> 1; if (vl[m] < i) lo = m; else hi = m; }
+        const int ea = vl[lo], eb = vl[hi], xa = pv[ea], xb = pv[eb];
+        const int den = eb - ea, twoden = 2 * den;
+        const int num = xa * den + (xb - xa) * (i - ea);    // 2 * den * X on the edge; column = X / 2
+        const int c = LOWER ? (num >= 0 ? (num + twoden - 1) / twoden : -((-num) / twoden))      // ceil
+                            : (num >= 0 ? num / twoden : -((-num + twoden - 1) / twoden));       // floor
+        bound[2 * r + (LOWER ? 0 : 1)] = c;
     }
 }
 __global__ __launch_bounds__(128) void k_convex(int n_saved, const int32_t *__restrict__ geo, const long long *__restrict__ row_off,
-                                                const int32_t *__restrict__ rowext, long long *sums, int hmax)
+                                                const int32_t *__restrict__ rowext, long long *sums, int hlo, int hhi)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char hull_smem[];
-    int *fl = (int *)hull_smem;                             // first / last column per row
-    int *cmin = fl + 2 * hmax, *cmax = cmin + hmax;
     const int s = blockIdx.x;
     const int h = geo[8 * (size_t)s + 4];
+    if (h <= hlo || h > hhi) return;                        // another size class
+    const int np = 2 * h + 1;
+    int *fl = (int *)hull_smem;                             // first / last column per row; later the two column bounds
+    int *pvl = fl + 2 * hhi, *pvu = pvl + (2 * hhi + 1), *vll = pvu + (2 * hhi + 1), *vlu = vll + (2 * hhi + 1);
     long long *q = sums + (size_t)s * PSEG_NSUMS;
     const int32_t *re = rowext + 2 * row_off[s];
     for (int i = threadIdx.x; i < 2 * h; i += 128) fl[i] = re[i];
     __syncthreads();
-    if (threadIdx.x < 64) hull_march<true>(fl, h, cmin, threadIdx.x);
-    else hull_march<false>(fl, h, cmax, threadIdx.x - 64);
+    for (int i = threadIdx.x; i < np; i += 128) {
+        const int r = i >> 1;
+        int l, u;
+        if (i & 1) { l = 2 * fl[2 * r] - 1; u = 2 * fl[2 * r + 1] + 1; }
+        else {
+            const int la = r > 0 ? 2 * fl[2 * r - 2] : 0x3fffffff, lb = r < h ? 2 * fl[2 * r] : 0x3fffffff;
+            const int ua = r > 0 ? 2 * fl[2 * r - 1] : -0x3fffffff, ub = r < h ? 2 * fl[2 * r + 1] : -0x3fffffff;
+            l = la < lb ? la : lb; u = ua > ub ? ua : ub;
+        }
+        pvl[i] = l; pvu[i] = u;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) hull_chain<true>(pvl, np, vll, fl, h, threadIdx.x);
+    else hull_chain<false>(pvu, np, vlu, fl, h, threadIdx.x - 64);
     __syncthreads();
     unsigned long long cnt = 0;
     for (int r = threadIdx.x; r < h; r += 128)
-        if (cmax[r] >= cmin[r]) cnt += (unsigned long long)(cmax[r] - cmin[r] + 1);
+        if (fl[2 * r + 1] >= fl[2 * r]) cnt += (unsigned long long)(fl[2 * r + 1] - fl[2 * r] + 1);
     cnt = wave_sum_u64(cnt);
     if ((threadIdx.x & 63) == 0 && cnt) atomicAdd((unsigned long long *)&q[14], cnt);
 }
@@ -1464,12 +1470,17 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
                            (uint8_t *)ctx->crops_mask.p, d_sums, (const long long *)ctx->bits_off.p,
                            (int32_t *)ctx->maskbits.p, (const int32_t *)ctx->band_obj.p);
         const int hmax = (int)h_tot[3];
-        const size_t hull_lds = (size_t)hmax * 16 + 16;
-        if (hull_lds > 150 * 1024) return fail(ctx, PSEG_ERR_CAPACITY, "saved object too tall for the convex-hull kernel");
-        if (hull_lds > 48 * 1024)
-            HIPCHK(hipFuncSetAttribute((const void *)k_convex, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hull_lds));
-        hipLaunchKernelGGL(k_convex, dim3(n_saved), dim3(128), hull_lds, st, n_saved, (const int32_t *)geo,
-                           (const long long *)ctx->bits_off.p, (const int32_t *)ctx->maskbits.p, d_sums, hmax);
+        // two size classes: objects up to 256 rows keep 10 KB of LDS per block, the rest is sized by the tallest one
+        const int hsmall = hmax < 256 ? hmax : 256;
+        const size_t lds_small = (size_t)hsmall * HULL_LDS_PER_ROW + 64, lds_big = (size_t)hmax * HULL_LDS_PER_ROW + 64;
+        if (lds_big > 150 * 1024) return fail(ctx, PSEG_ERR_CAPACITY, "saved object too tall for the convex-hull kernel (limit 3800 rows)");
+        if (lds_big > 48 * 1024)
+            HIPCHK(hipFuncSetAttribute((const void *)k_convex, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big));
+        hipLaunchKernelGGL(k_convex, dim3(n_saved), dim3(128), lds_small, st, n_saved, (const int32_t *)geo,
+                           (const long long *)ctx->bits_off.p, (const int32_t *)ctx->maskbits.p, d_sums, 0, hsmall);
+        if (hmax > hsmall)
+            hipLaunchKernelGGL(k_convex, dim3(n_saved), dim3(128), lds_big, st, n_saved, (const int32_t *)geo,
+                               (const long long *)ctx->bits_off.p, (const int32_t *)ctx->maskbits.p, d_sums, hsmall, hmax);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(ctx->ev[5], st));
