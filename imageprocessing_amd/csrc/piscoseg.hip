@@ -295,49 +295,51 @@ __device__ __forceinline__ uint2 ld_stream(const uint8_t *p)
     u32x2_t v = __builtin_nontemporal_load((const u32x2_t *)p);
     return make_uint2(v.x, v.y);
 }
+__device__ __forceinline__ uint32_t pkadd(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, (u16x2_t)(__builtin_bit_cast(u16x2_t, a) + __builtin_bit_cast(u16x2_t, b))); }
 struct BgEmit {
     uint8_t *cleaned, *bits8; uint4 *partials;              // real outputs
     uint8_t *t_cleaned, *t_bits8; uint4 *t_partials;        // trash rows: where a disabled step stores (keeps the loop branch-free)
-    size_t P, strip; uint2 inm; uint32_t kthr, thr_en; int thr_hi; uint32_t nwaves, wave;
+    size_t P; uint32_t off8, strip32; uint2 inm; uint32_t kadd, inm8; uint32_t nwaves, wave;
     uint32_t act;          // 0xffffffff for strips inside the frame, 0 for the padding lanes of the last wave
 };
-// bit 7 of every byte of x that is >= t (1 <= t <= 255), kt = t (t <= 128) or t-128, replicated
-__device__ __forceinline__ uint32_t bytes_ge(uint32_t x, uint32_t kt, int hi)
-{
-    uint32_t y = ((x & 0x7f7f7f7fu) | 0x80808080u) - kt;
-    uint32_t hm = hi ? 0xffffffffu : 0u;                    // branch-free select between (y & x) and (y | x)
-    return (((y & x) & hm) | ((y | x) & ~hm)) & 0x80808080u;
-}
 __device__ __forceinline__ uint32_t gather4(uint32_t r)     // bits 7,15,23,31 -> bits 0..3
 {
     r >>= 7; r |= r >> 7; r |= r >> 14;
     return r & 0xfu;
 }
 // frame s: cleaned = 255 - |img - bg| (bg_correction.py:80-81), the four sums and the threshold bits
-// (detection.py:178-202).  en is wave-uniform; a disabled call stores into the trash rows.
-__device__ __forceinline__ void bg_emit(const BgEmit &E, uint2 img, Px8 bg, int s, bool en)
+// (detection.py:178-202).  c = px_split(img).  en is wave-uniform; a disabled call stores into the trash rows.
+__device__ __forceinline__ void bg_emit(const BgEmit &E, uint2 img, Px8 c, Px8 bg, int s, bool en)
 {
-    Px8 c = px_split(img);
     uint32_t de0 = pksub(pkmax(c.e0, bg.e0), pkmin(c.e0, bg.e0)), do0 = pksub(pkmax(c.o0, bg.o0), pkmin(c.o0, bg.o0));
     uint32_t de1 = pksub(pkmax(c.e1, bg.e1), pkmin(c.e1, bg.e1)), do1 = pksub(pkmax(c.o1, bg.o1), pkmin(c.o1, bg.o1));
     uint2 corr = make_uint2(__builtin_amdgcn_perm(do0, de0, 0x06020400), __builtin_amdgcn_perm(do1, de1, 0x06020400));
     // every store is unconditional (disabled steps and padding lanes write to the trash rows): with no
     // branch in the loop body the compiler counts the outstanding loads exactly (vmcnt counts stores too)
     const bool real = en && E.act;
-    uint8_t *pc = real ? E.cleaned + (size_t)s * E.P : E.t_cleaned;
+    uint8_t *pc = real ? E.cleaned + (size_t)s * E.P : E.t_cleaned;          // wave-uniform bases, 32-bit lane offsets
     uint8_t *pb = real ? E.bits8 + (size_t)s * (E.P / 8) : E.t_bits8;
     uint4 *pp = en ? E.partials + (size_t)s * E.nwaves : E.t_partials;
-    *(uint2 *)(pc + E.strip * 8) = make_uint2(~corr.x, ~corr.y);
+    *(uint2 *)(pc + E.off8) = make_uint2(~corr.x, ~corr.y);
     uint2 cm = make_uint2(corr.x & E.inm.x, corr.y & E.inm.y);
     img.x &= E.act; img.y &= E.act;
     uint32_t s0 = __builtin_amdgcn_sad_u8(img.x, 0u, __builtin_amdgcn_sad_u8(img.y, 0u, 0u));
     uint32_t s1 = __builtin_amdgcn_udot4(img.x, img.x, __builtin_amdgcn_udot4(img.y, img.y, 0u, false), false);
     uint32_t s2 = __builtin_amdgcn_sad_u8(cm.x, 0u, __builtin_amdgcn_sad_u8(cm.y, 0u, 0u));
     uint32_t s3 = __builtin_amdgcn_udot4(cm.x, cm.x, __builtin_amdgcn_udot4(cm.y, cm.y, 0u, false), false);
-    uint32_t b = (gather4(bytes_ge(cm.x, E.kthr, E.thr_hi)) | (gather4(bytes_ge(cm.y, E.kthr, E.thr_hi)) << 4)) & E.thr_en;
-    pb[E.strip] = (uint8_t)b;
-    s0 = wave_sum63(s0); s1 = wave_sum63(s1); s2 = wave_sum63(s2); s3 = wave_sum63(s3);
-    if ((threadIdx.x & 63) == 63) pp[E.wave] = make_uint4(s0, s1, s2, s3);
+    // threshold bits: d + (0x8000 - t) has bit 15 set iff d >= t (d < 256); the flag bytes of the four registers are
+    // gathered with two byte permutes, the mask is applied on the 8 result bits
+    uint32_t fe0 = pkadd(de0, E.kadd), fo0 = pkadd(do0, E.kadd), fe1 = pkadd(de1, E.kadd), fo1 = pkadd(do1, E.kadd);
+    uint32_t lo4 = __builtin_amdgcn_perm(fo0, fe0, 0x07030501) & 0x80808080u, hi4 = __builtin_amdgcn_perm(fo1, fe1, 0x07030501) & 0x80808080u;
+    uint32_t b = (gather4(lo4) | (gather4(hi4) << 4)) & E.inm8;
+    pb[E.strip32] = (uint8_t)b;
+    // wave sums, valid in lane 63: sum x and sum c (<= 2040 per lane) travel packed in one register until the last step
+    uint32_t p = s0 | (s2 << 16);
+    p = dpp_add<0x111, 0xf>(p); p = dpp_add<0x112, 0xf>(p); p = dpp_add<0x114, 0xf>(p); p = dpp_add<0x118, 0xf>(p);
+    p = dpp_add<0x142, 0xa>(p);                                            // <= 65280 per half: no carry yet
+    const uint32_t q = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p, 0x143, 0xc, 0xf, false);
+    s1 = wave_sum63(s1); s3 = wave_sum63(s3);
+    if ((threadIdx.x & 63) == 63) pp[E.wave] = make_uint4((p & 0xffffu) + (q & 0xffffu), s1, (p >> 16) + (q >> 16), s3);
 }
 
 // Per-thread state.  The 12-frame history of raw pixels lives in an LDS ring (dynamic slot index,
@@ -345,7 +347,7 @@ __device__ __forceinline__ void bg_emit(const BgEmit &E, uint2 img, Px8 bg, int 
 // with compile-time phases (loop unrolled by 4).
 struct BgRegs {
     uint2 pf[4];           // frames k .. k+3 (pf[PH] is the frame of the current step)
-    uint2 prev;            // frame k-1
+    Px8 prev;              // frame k-1, split
     Px8 mp, t2[2], t4[4], t8[4], last;
 };
 #define BG_SLOTS 16
@@ -355,18 +357,19 @@ __device__ __forceinline__ void bg_step(BgRegs &R, uint2 *ring, const BgEmit &E,
 {
     const uint2 cur = R.pf[PH];
     int kn = k + 4 <= kend ? k + 4 : kend;                  // clamped prefetch: always a valid frame
-    R.pf[PH] = ld_stream(src + (size_t)kn * E.P);
+    R.pf[PH] = ld_stream(src + (size_t)kn * E.P + E.off8);  // src is wave-uniform
     ring[(k & (BG_SLOTS - 1)) * 256] = cur;
     const uint2 old = ring[((k - 11) & (BG_SLOTS - 1)) * 256];   // frame k-11 (zeros during warm-up)
-    Px8 m = px_min(px_split(R.prev), px_split(cur));        // pair minimum m[k-1]
+    const Px8 cs = px_split(cur);
+    Px8 m = px_min(R.prev, cs);                             // pair minimum m[k-1]
     if (k == a) m = Px8{0, 0, 0, 0};                         // no pair yet at the first frame of the chunk
-    R.prev = cur;
+    R.prev = cs;
     Px8 t2 = px_max(m, R.mp); R.mp = m;
     Px8 t4 = px_max(t2, R.t2[(PH + 1) & 1]); R.t2[(PH + 1) & 1] = t2;
     Px8 t8 = px_max(t4, R.t4[(PH + 3) & 3]); R.t4[(PH + 3) & 3] = t4;
     Px8 t11 = px_max(t8, R.t8[PH & 3]); R.t8[(PH + 3) & 3] = t8;
     R.last = t11;
-    bg_emit(E, old, t11, k - 11, k - 11 >= a && k < n - 1);
+    bg_emit(E, old, px_split(old), t11, k - 11, k - 11 >= a && k < n - 1);
 }
 
 // grid = (ceil(P/2048), chunks); chunk c emits frames [bounds[c], bounds[c+1])
@@ -382,28 +385,29 @@ __global__ __launch_bounds__(256, 4) void k_bg_stream(const uint8_t *__restrict_
     const int a = bounds[blockIdx.y], b = bounds[blockIdx.y + 1];
     const int kend = (b == n) ? n - 1 : b + 10;
     BgEmit E;
-    E.cleaned = cleaned; E.bits8 = bits8; E.partials = partials; E.P = P; E.strip = strip;
+    E.cleaned = cleaned; E.bits8 = bits8; E.partials = partials; E.P = P;
+    E.strip32 = (uint32_t)strip; E.off8 = (uint32_t)strip * 8u;             // P <= 2^29: lane offsets fit 32 bits
     E.t_cleaned = trash; E.t_bits8 = trash + P; E.t_partials = (uint4 *)(trash + P + P / 8);
     E.inm = make_uint2(0xffffffffu, 0xffffffffu);
     if (mask) { uint2 m = *(const uint2 *)(mask + strip * 8); E.inm = make_uint2(eq255_4(m.x), eq255_4(m.y)); }
     E.act = act ? 0xffffffffu : 0u;
     E.inm.x &= E.act; E.inm.y &= E.act;
-    int t1 = thr + 1;                                       // pixel > thr  <=>  pixel >= thr + 1
-    E.thr_en = (t1 >= 1 && t1 <= 255) ? 0xffu : 0u;       // threshold outside 0..254: no pixel passes
-    E.kthr = E.thr_en ? (uint32_t)(t1 <= 128 ? t1 : t1 - 128) * 0x01010101u : 0x01010101u;
-    E.thr_hi = t1 > 128;
+    const int t1 = thr + 1;                                 // pixel > thr  <=>  pixel >= thr + 1
+    const bool thr_ok = t1 >= 1 && t1 <= 255;               // threshold outside 0..254: no pixel passes
+    E.kadd = thr_ok ? (uint32_t)(0x8000 - t1) * 0x00010001u : 0u;
+    E.inm8 = thr_ok ? (gather4(E.inm.x & 0x80808080u) | (gather4(E.inm.y & 0x80808080u) << 4)) : 0u;
     E.nwaves = gridDim.x * 4; E.wave = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const uint8_t *src = frames + strip * 8;
+    const uint8_t *src = frames;
     uint2 *ring = lds + threadIdx.x;
 #pragma unroll
     for (int q = 0; q < BG_SLOTS; q++) ring[q * 256] = make_uint2(0, 0);
     BgRegs R;
     const Px8 z = {0, 0, 0, 0};
-    R.mp = z; R.last = z; R.prev = make_uint2(0, 0);
+    R.mp = z; R.last = z; R.prev = z;
     for (int i = 0; i < 2; i++) R.t2[i] = z;
     for (int i = 0; i < 4; i++) { R.t4[i] = z; R.t8[i] = z; }
 #pragma unroll
-    for (int i = 0; i < 4; i++) R.pf[i] = ld_stream(src + (size_t)(a + i <= kend ? a + i : kend) * P);
+    for (int i = 0; i < 4; i++) R.pf[i] = ld_stream(src + (size_t)(a + i <= kend ? a + i : kend) * P + E.off8);
     int k = a;
     for (; k + 3 <= kend; k += 4) {                         // branch-free body: counted waits keep 4 loads in flight
         bg_step<0>(R, ring, E, src, k, a, kend, n);
@@ -416,7 +420,10 @@ __global__ __launch_bounds__(256, 4) void k_bg_stream(const uint8_t *__restrict_
     if (k + 2 <= kend) bg_step<2>(R, ring, E, src, k + 2, a, kend, n);
     if (b == n) {                                           // the last 12 frames share bg[n-12] = T11 of the final step
 #pragma unroll 1
-        for (int i = n - 12; i < n; i++) bg_emit(E, ld_stream(src + (size_t)i * P), R.last, i, true);
+        for (int i = n - 12; i < n; i++) {
+            const uint2 img = ld_stream(src + (size_t)i * P + E.off8);
+            bg_emit(E, img, px_split(img), R.last, i, true);
+        }
     }
 }
 
