@@ -70,6 +70,7 @@ struct pseg_ctx {
     int bounds_n = -1, bounds_chunks = -1;
     int bg_chunks = 1;            // time chunks of the streaming background kernel (PSEG_BG_CHUNKS)
     bool force_generic = false;   // PSEG_BG_GENERIC=1: use the 12x-read reference kernel (debug / cross-check)
+    bool no_bands = false;        // PSEG_NO_BANDS=1: label with the global union-find only (the path of very dense frames)
     // host results
     HostBuf h_frame_row_offset, h_frame_n_contours, h_frame_valid, h_frame_mean, h_frame_std, h_area, h_saved8, h_props;
     int64_t crop_bytes = 0;
@@ -587,8 +588,104 @@ __global__ __launch_bounds__(256) void k_runs(SegState S, int nrows)
     }
 }
 __global__ void k_init(SegState S, int nfg, int nt) { size_t g = GTID; if (g < (size_t)nt) init_body(S, (int)g, nfg); }
-__global__ void k_fg_union(SegState S, int nfg) { size_t g = GTID; if (g < (size_t)nfg) fg_union_body(S, (int)g); }
-__global__ void k_bg_union(SegState S, int nfg, int nt) { size_t g = GTID; if (g < (size_t)nt) bg_union_body(S, (int)g, nfg); }
+__global__ void k_fg_union(SegState S, int nfg, int bandh) { size_t g = GTID; if (g < (size_t)nfg) fg_union_body(S, (int)g, bandh); }
+__global__ void k_bg_union(SegState S, int nfg, int nt, int bandh) { size_t g = GTID; if (g < (size_t)nt) bg_union_body(S, (int)g, nfg, bandh); }
+
+// ---- band-local labelling in LDS ----------------------------------------------------------------------------------
+// Block = one band of BAND_H rows of one frame.  The band's runs and gaps are united with a union-find that lives in
+// LDS (same rules as fg_union_body / bg_union_elem, local indices), flattened, and written to the global parent arrays
+// as global indices; k_fg_union / k_bg_union then only unite across the band boundaries and k_flatten finishes.  The
+// frame-connected background (smallest background index of the frame, seg_b0) is the virtual node -1 here.  Also does
+// the work of k_init for the band.  Used when no band of the batch has more than BAND_CAP runs (k_scan_rows reports
+// the maximum); otherwise the host takes the global path.
+#define BAND_H 128
+#define BAND_CAP 2048
+__device__ __forceinline__ int lds_find(int *par, int a)
+{
+    if (a < 0) return -1;
+    int p = par[a];
+    while (p != a && p >= 0) {
+        int g = par[p];
+        if (g != p) par[a] = g;                              // path halving (g may be the virtual root -1)
+        a = p; p = g;
+    }
+    return p < 0 ? -1 : a;
+}
+__device__ __forceinline__ void lds_union(int *par, int a, int b)
+{
+    for (int guard = 0; guard < (1 << 24); guard++) {
+        a = lds_find(par, a); b = lds_find(par, b);
+        if (a == b) return;
+        const int hi = a > b ? a : b, lo = a > b ? b : a;    // hi >= 0; lo may be the virtual root
+        const int old = atomicMin(&par[hi], lo);
+        if (old == hi) return;
+        a = old; b = lo;
+    }
+}
+__global__ __launch_bounds__(256) void k_band_label(SegState S)
+{
+    __shared__ uint32_t lx[BAND_CAP];                     // run_x of the band's runs
+    __shared__ uint16_t ly[BAND_CAP];                     // band-local row of every run
+    __shared__ int fgp[BAND_CAP], bgp[BAND_CAP + BAND_H];
+    __shared__ int lrow[BAND_H + 1];                      // local index of the first run of every row
+    const int f = blockIdx.y, y0 = blockIdx.x * BAND_H, H = S.H;
+    const int nr = (y0 + BAND_H <= H) ? BAND_H : H - y0;  // rows in this band
+    const uint32_t *ro = S.rowoff + (size_t)f * (H + 1) + y0;
+    const int R0 = (int)(S.framebase[f] + ro[0]);         // global index of the band's first run
+    const int nb = (int)(ro[nr] - ro[0]);                 // runs in the band (<= BAND_CAP, checked by the host)
+    const int B0g = seg_b0(S, f), Bb = R0 + f * H + y0;   // global background indices: frame-connected / band base
+    for (int t = threadIdx.x; t <= nr; t += 256) lrow[t] = (int)(ro[t] - ro[0]);
+    __syncthreads();
+    // init (k_init's work for this band)
+    for (int i = threadIdx.x; i < nb; i += 256) {
+        const int r = R0 + i;
+        const int y = (int)(S.run_fy[r] & 0xffffu), yl = y - y0;
+        lx[i] = S.run_x[r]; ly[i] = (uint16_t)yl; fgp[i] = i;
+        const int j = i - lrow[yl];
+        bgp[i + yl] = (j == 0 || y == 0 || y == H - 1) ? -1 : i + yl;
+        S.bg_left[Bb + i + yl] = j == 0 ? -1 : r - 1;
+        S.minx[r] = 0x7fffffff; S.maxx[r] = -1; S.maxy[r] = -1; S.area2[r] = 0;
+    }
+    for (int yl = threadIdx.x; yl < nr; yl += 256) {      // trailing gap of every row
+        const int g = lrow[yl + 1] + yl;
+        bgp[g] = -1;
+        S.bg_left[Bb + g] = lrow[yl + 1] == lrow[yl] ? -1 : R0 + lrow[yl + 1] - 1;
+    }
+    __syncthreads();
+    // unions with the previous row of the band (rows yl >= 1)
+    for (int i = threadIdx.x; i < nb + nr; i += 256) {
+        int yl, j, n;
+        if (i < nb) { yl = ly[i]; j = i - lrow[yl]; n = lrow[yl + 1] - lrow[yl]; }
+        else { yl = i - nb; n = lrow[yl + 1] - lrow[yl]; j = n; }                 // trailing gap of row yl
+        if (yl == 0) continue;
+        const int ps = lrow[yl - 1], pn = lrow[yl] - ps, rs = lrow[yl];
+        if (i < nb && pn > 0) {                              // foreground, 8-connectivity (fg_union_body)
+            const int lo = (int)(lx[i] & 0xffffu) - 1, hi = (int)(lx[i] >> 16) + 1;
+            int a = ps, b = ps + pn;                         // first q with xe_q >= lo
+            while (a < b) { const int m = (a + b) >> 1; if ((int)(lx[m] >> 16) >= lo) b = m; else a = m + 1; }
+            for (int q = a; q < ps + pn && (int)(lx[q] & 0xffffu) <= hi; q++) lds_union(fgp, i, q);
+        }
+        {                                                    // background, 4-connectivity (bg_union_elem)
+            const int ga = j == 0 ? -1 : (int)(lx[rs + j - 1] >> 16) + 1;
+            const int ge = j == n ? S.W : (int)(lx[rs + j] & 0xffffu) - 1;
+            const int g = rs + j + yl, pb = ps + (yl - 1);
+            int lo = 0, hi = pn;                             // first gap of the previous row whose right end >= ga
+            while (lo < hi) { const int m = (lo + hi) >> 1; if ((int)(lx[ps + m] & 0xffffu) >= ga + 1) hi = m; else lo = m + 1; }
+            for (int q = lo; q <= pn; q++) {
+                const int qa = q == 0 ? -1 : (int)(lx[ps + q - 1] >> 16) + 1;
+                if (qa > ge) break;
+                lds_union(bgp, g, pb + q);
+            }
+        }
+    }
+    __syncthreads();
+    // flatten and publish as global indices
+    for (int i = threadIdx.x; i < nb + nr; i += 256) {
+        if (i < nb) S.fg_parent[R0 + i] = R0 + lds_find(fgp, i);
+        const int rt = lds_find(bgp, i);
+        S.bg_parent[Bb + i] = rt < 0 ? B0g : Bb + rt;
+    }
+}
 __global__ void k_flatten(SegState S, int nfg, int nbg)
 {
     size_t g = GTID;
@@ -626,7 +723,7 @@ __global__ __launch_bounds__(256) void k_bbox(SegState S, int nfg)
 __global__ void k_area(SegState S, int nfy) { size_t g = GTID; if (g < (size_t)nfy) area_body(S, (int)g); }
 
 // exclusive scan of rowcnt inside each frame (block per frame); ftot[f] = runs in frame f
-__global__ __launch_bounds__(256) void k_scan_rows(SegState S, uint32_t *ftot)
+__global__ __launch_bounds__(256) void k_scan_rows(SegState S, uint32_t *ftot, uint32_t *bandmax)
 {
     __shared__ uint32_t sh[256];
     __shared__ uint32_t carry;
@@ -651,6 +748,16 @@ __global__ __launch_bounds__(256) void k_scan_rows(SegState S, uint32_t *ftot)
         __syncthreads();
     }
     if (threadIdx.x == 0) { S.rowoff[(size_t)f * (H + 1) + H] = carry; ftot[f] = carry; }
+    // largest number of runs in one band of BAND_H rows (decides between k_band_label and the global path)
+    __syncthreads();
+    uint32_t bm = 0;
+    for (int b = threadIdx.x; b * BAND_H < H; b += 256) {
+        const int ya = b * BAND_H, yb = ya + BAND_H < H ? ya + BAND_H : H;
+        const uint32_t c = S.rowoff[(size_t)f * (H + 1) + yb] - S.rowoff[(size_t)f * (H + 1) + ya];
+        bm = c > bm ? c : bm;
+    }
+    for (int o = 32; o > 0; o >>= 1) { uint32_t t = __shfl_xor(bm, o, 64); bm = t > bm ? t : bm; }
+    if ((threadIdx.x & 63) == 0 && bm) atomicMax(bandmax, bm);
 }
 
 // exclusive scan over the frames by one block: out[0..F] (strided input / output)
@@ -1208,6 +1315,7 @@ extern "C" int pseg_create(int device, int H, int W, int max_frames, pseg_ctx **
     ctx->own_stream = true;
     if (const char *e = getenv("PSEG_BG_CHUNKS")) ctx->bg_chunks = atoi(e) > 0 ? atoi(e) : 1;
     if (const char *e = getenv("PSEG_BG_GENERIC")) ctx->force_generic = atoi(e) != 0;
+    if (const char *e = getenv("PSEG_NO_BANDS")) ctx->no_bands = atoi(e) != 0;
     for (auto &e : ctx->ev) if (hipEventCreate(&e) != hipSuccess) { delete ctx; return PSEG_ERR_HIP; }
     *out = ctx;
     return PSEG_OK;
@@ -1373,7 +1481,7 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
     S.valid = (const uint8_t *)ctx->valid_dev.p;
     ENSURE(ctx->rowcnt, (size_t)n * H * 4);
     ENSURE(ctx->rowoff, (size_t)n * (H + 1) * 4);
-    ENSURE(ctx->framebase, (size_t)(n + 1) * 4);
+    ENSURE(ctx->framebase, (size_t)(n + 2) * 4);             // [n] = total runs, [n+1] = largest band (read back together)
     { int r_ = head_setup(ctx, n); if (r_) return r_; }
     S.rowcnt = (uint32_t *)ctx->rowcnt.p; S.rowoff = (uint32_t *)ctx->rowoff.p; S.framebase = (uint32_t *)ctx->framebase.p;
     uint32_t *ftot = (uint32_t *)ctx->ftot.p;            // [n] run totals | [3n] rank totals | [n+1] rowbase | [n+1] savedbase
@@ -1386,12 +1494,13 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
         hipLaunchKernelGGL(k_mask_count, dim3(256), dim3(256), 0, st, mask, P, (unsigned long long *)ctx->maskcnt.p);
     }
     hipLaunchKernelGGL(k_runs<false>, dim3(nblocks((size_t)n * H, 4 * RUNS_RPW)), dim3(256), 0, st, S, n * H);
-    hipLaunchKernelGGL(k_scan_rows, dim3(n), dim3(256), 0, st, S, ftot);
+    HIPCHK(hipMemsetAsync(S.framebase + n + 1, 0, 4, st));
+    hipLaunchKernelGGL(k_scan_rows, dim3(n), dim3(256), 0, st, S, ftot, S.framebase + n + 1);
     hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(256), 0, st, (const uint32_t *)ftot, S.framebase, n, 1, 1);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(ctx->pin_nfg.p, S.framebase + n, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(ctx->pin_nfg.p, S.framebase + n, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    const uint32_t nfg_u = *(const volatile uint32_t *)ctx->pin_nfg.p;
+    const uint32_t nfg_u = ((const volatile uint32_t *)ctx->pin_nfg.p)[0], bandmax = ((const volatile uint32_t *)ctx->pin_nfg.p)[1];
     if (nfg_u > 0x3fffffffu) return fail(ctx, PSEG_ERR_CAPACITY, "too many foreground runs");
     const int nfg = (int)nfg_u, nbg = nfg + n * H;
     const size_t cap = (size_t)(nfg > 0 ? nfg : 1);
@@ -1409,9 +1518,16 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
     int32_t *objlabel = (int32_t *)ctx->objlabel.p, *objflag = (int32_t *)ctx->objflag.p;
 
     if (nfg > 0) hipLaunchKernelGGL(k_runs<true>, dim3(nblocks((size_t)n * H, 4 * RUNS_RPW)), dim3(256), 0, st, S, n * H);
-    hipLaunchKernelGGL(k_init, dim3(nblocks(nbg)), dim3(256), 0, st, S, nfg, nbg);
-    if (nfg > 0) hipLaunchKernelGGL(k_fg_union, dim3(nblocks(nfg)), dim3(256), 0, st, S, nfg);
-    hipLaunchKernelGGL(k_bg_union, dim3(nblocks(nbg)), dim3(256), 0, st, S, nfg, nbg);
+    if (bandmax <= BAND_CAP && !ctx->no_bands) {
+        // bands of BAND_H rows are labelled in LDS; the global kernels only unite across the band boundaries
+        hipLaunchKernelGGL(k_band_label, dim3((H + BAND_H - 1) / BAND_H, n), dim3(256), 0, st, S);
+        if (nfg > 0) hipLaunchKernelGGL(k_fg_union, dim3(nblocks(nfg)), dim3(256), 0, st, S, nfg, BAND_H);
+        hipLaunchKernelGGL(k_bg_union, dim3(nblocks(nbg)), dim3(256), 0, st, S, nfg, nbg, BAND_H);
+    } else {
+        hipLaunchKernelGGL(k_init, dim3(nblocks(nbg)), dim3(256), 0, st, S, nfg, nbg);
+        if (nfg > 0) hipLaunchKernelGGL(k_fg_union, dim3(nblocks(nfg)), dim3(256), 0, st, S, nfg, 0);
+        hipLaunchKernelGGL(k_bg_union, dim3(nblocks(nbg)), dim3(256), 0, st, S, nfg, nbg, 0);
+    }
     hipLaunchKernelGGL(k_flatten, dim3(nblocks(nbg)), dim3(256), 0, st, S, nfg, nbg);
     if (nfg > 0) {
         hipLaunchKernelGGL(k_resolve_ext, dim3(nblocks(nfg)), dim3(256), 0, st, S, nfg);

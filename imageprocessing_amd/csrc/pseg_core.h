@@ -129,10 +129,11 @@ PSEG_HD void init_body(const SegState &S, int t, int nfg)
 }
 
 // ---- 3. foreground unions, 8-connectivity (thread per run) -----------------------------------
-PSEG_HD void fg_union_body(const SegState &S, int r)
+// bandh > 0: only rows on a band boundary (y % bandh == 0) -- the rows inside a band were united in LDS
+PSEG_HD void fg_union_body(const SegState &S, int r, int bandh = 0)
 {
     int y = (int)(S.run_fy[r] & 0xffffu), f = (int)(S.run_fy[r] >> 16);
-    if (y == 0) return;
+    if (y == 0 || (bandh > 0 && y % bandh != 0)) return;
     int p0 = seg_rowstart(S, f, y - 1), p1 = seg_rowstart(S, f, y);
     if (p0 == p1) return;
     int lo = run_xs(S, r) - 1, hi = run_xe(S, r) + 1;
@@ -162,13 +163,15 @@ PSEG_HD void bg_union_elem(const SegState &S, int f, int y, int j)
     }
 }
 // thread t < nfg : gap left of run t ; thread t >= nfg : trailing gap of row (t - nfg)
-PSEG_HD void bg_union_body(const SegState &S, int t, int nfg)
+PSEG_HD void bg_union_body(const SegState &S, int t, int nfg, int bandh = 0)
 {
     if (t < nfg) {
         int y = (int)(S.run_fy[t] & 0xffffu), f = (int)(S.run_fy[t] >> 16);
+        if (bandh > 0 && y % bandh != 0) return;
         bg_union_elem(S, f, y, t - seg_rowstart(S, f, y));
     } else {
         int fy = t - nfg, f = fy / S.H, y = fy % S.H;
+        if (bandh > 0 && y % bandh != 0) return;
         bg_union_elem(S, f, y, seg_rowcount(S, f, y));
     }
 }

@@ -72,11 +72,16 @@ def test_process_parity(gpu_seg_factory, H, W, n, seed, kw):
     helpers.compare_table(tab2, dets, H, W)
 
 
-def test_detect_noise_images(gpu_seg_factory):
-    """Dense random binary images: stresses nesting, pinches, spurs and the cumulative mask."""
+@pytest.mark.parametrize("H,no_bands", [(64, "0"), (64, "1"), (300, "0")])
+def test_detect_noise_images(monkeypatch, H, no_bands):
+    """Dense random binary images: stresses nesting, pinches, spurs and the cumulative mask.  Labelling runs once
+    through the LDS bands + boundary merge (H = 300: three bands, the last one short) and once through the global
+    union-find alone (the path of frames too dense for the bands)."""
     import torch
-    H, W, n = 64, 128, 24
-    seg = gpu_seg_factory(H, W)
+    from imageprocessing_amd.engine import Segmenter
+    monkeypatch.setenv("PSEG_NO_BANDS", no_bands)
+    W, n = 128, 24 if H == 64 else 6
+    seg = Segmenter(H, W, max_frames=n, device=0)
     rng = np.random.default_rng(5)
     cleaned = np.full((n, H, W), 255, np.uint8)
     for f in range(n):
@@ -88,6 +93,7 @@ def test_detect_noise_images(gpu_seg_factory):
     tab = seg.detect(torch.from_numpy(cleaned).cuda(), min_area_to_segment=2, min_area_to_save=20, labels=labels,
                      fetch_crops=True)
     helpers.compare_table(tab, dets, H, W, labels=labels.cpu().numpy())
+    seg.close()
 
 
 def test_disk_mask(gpu_seg_factory):
