@@ -62,7 +62,7 @@ struct pseg_ctx {
     bool head_on_host = false;    // pin_head holds this call's head (pseg_process reuses it for the raw statistics)
     // sparse workspaces
     DevBuf rowcnt, rowoff, framebase;
-    DevBuf run_x, run_fy, fg_parent, ext, gapl, bg_parent, bg_left, minx, maxx, maxy, area2, extrank,
+    DevBuf run_x, run_fy, fg_parent, ext, gapl, runlabel, bg_parent, bg_left, minx, maxx, maxy, area2, extrank,
         keptrank, savedrank, objlabel, objflag;
     DevBuf rows, saved_row, saved_geo, crop_off, bits_off, maskbits, crops_raw, crops_masked, crops_mask;
     bool have_bits = false;       // threshold plane + masked sums already produced by the bg kernel
@@ -856,35 +856,52 @@ __global__ void k_emit(SegState S, int nfg, double min_seg, double min_save, con
     if (saved) saved_row[(int)savedbase[f] + (nsaved - 1 - S.savedrank[r])] = i;
 }
 
-// label map: one dense pass writes every int32 exactly once.  Thread = 4 pixels
-// (one 16-byte store, 1 KiB per wave); the 4 threshold bits decide between a zero store and a run
-// lookup (binary search in the row's runs).  grid = (P/1024, frames).
+// label map: one dense pass writes every int32 exactly once.  Wave = one 256-pixel span of a row
+// (lane = 4 pixels = one 16-byte store; a block writes 4 consecutive spans, blocks sweep the map in address order --
+// the shape that streams at 6.8 TB/s when it only stores).  A span whose threshold bits are all zero is stored at once.
+// Otherwise the wave works together: the row's runs and their labels are loaded one per lane, the runs that meet the
+// span are broadcast one after the other (typically one or two) and every lane takes what falls on its pixels.
 typedef int32_t i32x4_t __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(256) void k_label_fill(SegState S, const int32_t *__restrict__ objlabel, int32_t *__restrict__ labels)
+__global__ void k_run_labels(SegState S, int nfg, const int32_t *__restrict__ objlabel, int32_t *__restrict__ runlabel)
 {
-    const size_t P = (size_t)S.H * S.W;
-    size_t pix = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (pix >= P) return;
-    int f = blockIdx.y;
-    uint32_t nib = (((const uint8_t *)S.bits)[((size_t)f * P + pix) >> 3] >> (pix & 4)) & 0xfu;
+    const size_t g = GTID;
+    if (g >= (size_t)nfg) return;
+    const int E = S.ext[g];
+    runlabel[g] = (S.fg_parent[g] == E) ? objlabel[E] : 0;  // components nested in holes keep 0
+}
+// grid = (ceil(W / 1024), H, frames): row and frame come from the block index (no divisions; at one KiB per wave the
+// kernel only streams at full rate while a wave spends a few dozen instructions)
+__global__ __launch_bounds__(256) void k_label_fill(SegState S, const int32_t *__restrict__ runlabel, int32_t *__restrict__ labels)
+{
+    const int lane = threadIdx.x & 63;
+    const int f = blockIdx.z, y = blockIdx.y;
+    const int x0 = blockIdx.x * 1024 + (threadIdx.x >> 6) * 256, x = x0 + 4 * lane;
+    if (x0 >= S.W) return;                                   // wave beyond the row end
+    const bool in = x < S.W;
+    const size_t rowpix = ((size_t)f * S.H + y) * S.W;
+    uint32_t nib = 0;
+    if (in) nib = (uint32_t)(((const uint8_t *)S.bits)[(rowpix + x) >> 3] >> (x & 4)) & 0xfu;
     i32x4_t out = {0, 0, 0, 0};
-    if (nib && S.valid[f]) {
-        int y = (int)(pix / S.W), x = (int)(pix - (size_t)y * S.W);
-        int rs = seg_rowstart(S, f, y), n = seg_rowcount(S, f, y);
-        int lo = 0, hi = n;                                  // first run with xe >= x
-        while (lo < hi) { int m = (lo + hi) >> 1; if (run_xe(S, rs + m) >= x) hi = m; else lo = m + 1; }
-        for (int q = rs + lo; q < rs + n; q++) {
-            int xs = run_xs(S, q), xe = run_xe(S, q);
-            if (xs > x + 3) break;
-            int E = S.ext[q];
-            int lab = (S.fg_parent[q] == E) ? objlabel[E] : 0;   // components nested in holes keep 0
-            if (xs <= x && x <= xe) out.x = lab;
-            if (xs <= x + 1 && x + 1 <= xe) out.y = lab;
-            if (xs <= x + 2 && x + 2 <= xe) out.z = lab;
-            if (xs <= x + 3 && x + 3 <= xe) out.w = lab;
+    if (__ballot(nib != 0) && S.valid[f]) {
+        const int rs = seg_rowstart(S, f, y), n = seg_rowcount(S, f, y);
+        for (int j0 = 0; j0 < n; j0 += 64) {
+            uint32_t rx = 0xffffu; int lab = 0;              // lanes past the row's runs: xs = 65535, xe = 0
+            if (j0 + lane < n) { rx = S.run_x[rs + j0 + lane]; lab = runlabel[rs + j0 + lane]; }
+            const int xs = (int)(rx & 0xffffu), xe = (int)(rx >> 16);
+            unsigned long long hit = __ballot(lab != 0 && xe >= x0 && xs <= x0 + 255);
+            while (hit) {
+                const int l = __builtin_ctzll(hit);
+                hit &= hit - 1;
+                const int a = __builtin_amdgcn_readlane(xs, l), b = __builtin_amdgcn_readlane(xe, l), lb = __builtin_amdgcn_readlane(lab, l);
+                if (a <= x && x <= b) out.x = lb;
+                if (a <= x + 1 && x + 1 <= b) out.y = lb;
+                if (a <= x + 2 && x + 2 <= b) out.z = lb;
+                if (a <= x + 3 && x + 3 <= b) out.w = lb;
+            }
+            if (__builtin_amdgcn_readlane(xs, 63) > x0 + 255) break;    // runs are sorted: nothing further meets the span
         }
     }
-    __builtin_nontemporal_store(out, (i32x4_t *)(labels + (size_t)f * P + pix));
+    if (in) __builtin_nontemporal_store(out, (i32x4_t *)(labels + rowpix + x));
 }
 
 // geometry of saved object s: geo[s*8] = f, x, y, w, h, root, words-per-row, row ; sz[s*3] = crop bytes,
@@ -1327,7 +1344,7 @@ extern "C" int pseg_destroy(pseg_ctx *ctx)
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->bits, &ctx->partials, &ctx->head, &ctx->outpack, &ctx->rowspans, &ctx->rowcnt,
-                      &ctx->rowoff, &ctx->framebase, &ctx->run_x, &ctx->run_fy, &ctx->fg_parent, &ctx->ext, &ctx->gapl,
+                      &ctx->rowoff, &ctx->framebase, &ctx->run_x, &ctx->run_fy, &ctx->fg_parent, &ctx->ext, &ctx->gapl, &ctx->runlabel,
                       &ctx->bg_parent, &ctx->bg_left, &ctx->minx, &ctx->maxx, &ctx->maxy, &ctx->area2,
                       &ctx->extrank, &ctx->keptrank, &ctx->savedrank, &ctx->objlabel, &ctx->objflag, &ctx->rows,
                       &ctx->saved_row, &ctx->saved_geo, &ctx->crop_off, &ctx->bits_off, &ctx->maskbits,
@@ -1571,7 +1588,10 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
     // (running the label fill on a second stream next to the crop / property kernels was measured: the fill takes 2.0 ms
     // instead of 0.93 ms when it shares the CUs, a net loss)
     if (labels) {
-        hipLaunchKernelGGL(k_label_fill, dim3(nblocks(P / 4), n), dim3(256), 0, st, S, (const int32_t *)objlabel, labels);
+        ENSURE(ctx->runlabel, cap * 4);
+        if (nfg > 0) hipLaunchKernelGGL(k_run_labels, dim3(nblocks(nfg)), dim3(256), 0, st, S, nfg, (const int32_t *)objlabel, (int32_t *)ctx->runlabel.p);
+        hipLaunchKernelGGL(k_label_fill, dim3((W + 1023) / 1024, H, n), dim3(256), 0, st, S,
+                           (const int32_t *)ctx->runlabel.p, labels);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(ctx->ev[4], st));
