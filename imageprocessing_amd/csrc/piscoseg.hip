@@ -448,17 +448,17 @@ __global__ __launch_bounds__(256) void k_threshold(const uint8_t *__restrict__ c
 
 // per-frame reduction of the block partials; fsums[f*4+k] u64.  If setvalid: valid[f] = std > 2,
 // decided exactly in integers: P*sum(x^2) - sum(x)^2 > 4*P^2   (bg_correction.py:71)
-__global__ __launch_bounds__(256) void k_reduce_partials(const uint32_t *__restrict__ partials, int nblk, unsigned long long P,
-                                                         unsigned long long *__restrict__ fsums, uint8_t *__restrict__ valid,
-                                                         int setvalid, int first, int count)
+__global__ __launch_bounds__(1024) void k_reduce_partials(const uint32_t *__restrict__ partials, int nblk, unsigned long long P,
+                                                          unsigned long long *__restrict__ fsums, uint8_t *__restrict__ valid,
+                                                          int setvalid, int first, int count)
 {
-    __shared__ unsigned long long red[4][4];
+    __shared__ unsigned long long red[16][4];
     int f = blockIdx.x;
     unsigned long long a[4] = {0, 0, 0, 0};
-    for (int b = threadIdx.x; b < nblk; b += 256) {
-        const uint32_t *p = partials + ((size_t)f * nblk + b) * 4;
-#pragma unroll
-        for (int k = 0; k < 4; k++) a[k] += p[k];
+    const uint4 *p4 = (const uint4 *)partials + (size_t)f * nblk;
+    for (int b = threadIdx.x; b < nblk; b += 1024) {
+        const uint4 v = p4[b];
+        a[0] += v.x; a[1] += v.y; a[2] += v.z; a[3] += v.w;
     }
 #pragma unroll
     for (int k = 0; k < 4; k++)
@@ -467,8 +467,8 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const uint32_t *__restr
     if (lane == 0) for (int k = 0; k < 4; k++) red[wv][k] = a[k];
     __syncthreads();
     if (threadIdx.x == 0) {
-        unsigned long long s[4];
-        for (int k = 0; k < 4; k++) s[k] = red[0][k] + red[1][k] + red[2][k] + red[3][k];
+        unsigned long long s[4] = {0, 0, 0, 0};
+        for (int w = 0; w < 16; w++) for (int k = 0; k < 4; k++) s[k] += red[w][k];
         for (int k = first; k < first + count; k++) fsums[(size_t)f * 4 + k] = s[k];
         if (setvalid) valid[f] = (P * s[1] - s[0] * s[0]) > 4ull * P * P;
     }
@@ -789,40 +789,36 @@ __global__ __launch_bounds__(256) void k_scan_small(const uint32_t *in, uint32_t
 
 // ranks of external roots / kept / saved objects inside each frame (block per frame).
 // ftot3[f*3+{0,1,2}] = number of external contours, kept, saved.
-__global__ __launch_bounds__(256) void k_rank(SegState S, double min_seg, double min_save, uint32_t *ftot3)
+__global__ __launch_bounds__(1024) void k_rank(SegState S, double min_seg, double min_save, uint32_t *ftot3)
 {
-    __shared__ uint32_t sh[3][256];
+    __shared__ uint32_t wtot[16][3];
     __shared__ uint32_t carry[3];
-    int f = blockIdx.x;
-    int r0 = (int)S.framebase[f], r1 = (int)S.framebase[f + 1];
+    const int f = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int r0 = (int)S.framebase[f], r1 = (int)S.framebase[f + 1];
     if (threadIdx.x < 3) carry[threadIdx.x] = 0;
     __syncthreads();
-    for (int base = r0; base < r1; base += 256) {
-        int r = base + threadIdx.x;
-        uint32_t v[3] = {0, 0, 0};
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (int base = r0; base < r1; base += 1024) {
+        const int r = base + threadIdx.x;
+        bool v0 = false, v1 = false, v2 = false;
         if (r < r1 && is_ext_root(S, r)) {
-            double area = 0.5 * (double)S.area2[r];
-            v[0] = 1;
-            v[1] = !(area < min_seg);                       // detection.py:223 ("< -> continue")
-            v[2] = v[1] && (area > min_save);               // detection.py:235
+            const double area = 0.5 * (double)S.area2[r];
+            v0 = true;
+            v1 = !(area < min_seg);                         // detection.py:223 ("< -> continue")
+            v2 = v1 && (area > min_save);                   // detection.py:235
         }
-        for (int k = 0; k < 3; k++) sh[k][threadIdx.x] = v[k];
+        const unsigned long long b0 = __ballot(v0), b1 = __ballot(v1), b2 = __ballot(v2);
+        if (lane == 0) { wtot[wv][0] = (uint32_t)__popcll(b0); wtot[wv][1] = (uint32_t)__popcll(b1); wtot[wv][2] = (uint32_t)__popcll(b2); }
         __syncthreads();
-        for (int o = 1; o < 256; o <<= 1) {
-            uint32_t t[3];
-            for (int k = 0; k < 3; k++) t[k] = threadIdx.x >= o ? sh[k][threadIdx.x - o] : 0;
-            __syncthreads();
-            for (int k = 0; k < 3; k++) sh[k][threadIdx.x] += t[k];
-            __syncthreads();
-        }
-        uint32_t c0[3] = {carry[0], carry[1], carry[2]};
+        uint32_t p0 = carry[0], p1 = carry[1], p2 = carry[2];
+        for (int w = 0; w < wv; w++) { p0 += wtot[w][0]; p1 += wtot[w][1]; p2 += wtot[w][2]; }
         if (r < r1) {
-            S.extrank[r] = (int32_t)(c0[0] + sh[0][threadIdx.x] - v[0]);
-            S.keptrank[r] = (int32_t)(c0[1] + sh[1][threadIdx.x] - v[1]);
-            S.savedrank[r] = (int32_t)(c0[2] + sh[2][threadIdx.x] - v[2]);
+            S.extrank[r] = (int32_t)(p0 + (uint32_t)__popcll(b0 & below));
+            S.keptrank[r] = (int32_t)(p1 + (uint32_t)__popcll(b1 & below));
+            S.savedrank[r] = (int32_t)(p2 + (uint32_t)__popcll(b2 & below));
         }
         __syncthreads();
-        if (threadIdx.x == 255) for (int k = 0; k < 3; k++) carry[k] = c0[k] + sh[k][255];
+        if (threadIdx.x == 1023) { carry[0] = p0 + wtot[15][0]; carry[1] = p1 + wtot[15][1]; carry[2] = p2 + wtot[15][2]; }
         __syncthreads();
     }
     if (threadIdx.x < 3) ftot3[f * 3 + threadIdx.x] = carry[threadIdx.x];
@@ -933,29 +929,28 @@ __global__ void k_saved_geo(const uint32_t *n_saved_p, const int32_t *saved_row,
 __global__ __launch_bounds__(1024) void k_scan_sizes(const unsigned long long *sz, const uint32_t *n_p, long long *crop_off,
                                                       long long *bits_off, long long *band_off, long long *totals)
 {
-    __shared__ unsigned long long sh[3][1024];
+    __shared__ unsigned long long wtot[16][3];
     __shared__ unsigned long long carry[3];
-    const int n = (int)*n_p;
+    const int n = (int)*n_p, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (threadIdx.x < 3) carry[threadIdx.x] = 0;
     __syncthreads();
     long long *outp[3] = {crop_off, bits_off, band_off};
     for (int base = 0; base < n; base += 1024) {
-        int i = base + threadIdx.x;
-        unsigned long long v[3] = {0, 0, 0};
+        const int i = base + threadIdx.x;
+        unsigned long long v[3] = {0, 0, 0}, inc[3];
         if (i < n) for (int k = 0; k < 3; k++) v[k] = sz[3 * (size_t)i + k];
-        for (int k = 0; k < 3; k++) sh[k][threadIdx.x] = v[k];
-        __syncthreads();
-        for (int o = 1; o < 1024; o <<= 1) {
-            unsigned long long t[3];
-            for (int k = 0; k < 3; k++) t[k] = threadIdx.x >= o ? sh[k][threadIdx.x - o] : 0;
-            __syncthreads();
-            for (int k = 0; k < 3; k++) sh[k][threadIdx.x] += t[k];
-            __syncthreads();
+        for (int k = 0; k < 3; k++) {                        // inclusive scan inside the wave
+            unsigned long long x = v[k];
+            for (int o = 1; o < 64; o <<= 1) { unsigned long long t = __shfl_up(x, o, 64); if (lane >= o) x += t; }
+            inc[k] = x;
         }
-        unsigned long long c0[3] = {carry[0], carry[1], carry[2]};
-        if (i < n) for (int k = 0; k < 3; k++) outp[k][i] = (long long)(c0[k] + sh[k][threadIdx.x] - v[k]);
+        if (lane == 63) for (int k = 0; k < 3; k++) wtot[wv][k] = inc[k];
         __syncthreads();
-        if (threadIdx.x == 1023) for (int k = 0; k < 3; k++) carry[k] = c0[k] + sh[k][1023];
+        unsigned long long pre[3] = {carry[0], carry[1], carry[2]};
+        for (int w = 0; w < wv; w++) for (int k = 0; k < 3; k++) pre[k] += wtot[w][k];
+        if (i < n) for (int k = 0; k < 3; k++) outp[k][i] = (long long)(pre[k] + inc[k] - v[k]);
+        __syncthreads();
+        if (threadIdx.x == 1023) for (int k = 0; k < 3; k++) carry[k] = pre[k] + inc[k];
         __syncthreads();
     }
     if (threadIdx.x < 3) { outp[threadIdx.x][n] = (long long)carry[threadIdx.x]; totals[threadIdx.x] = (long long)carry[threadIdx.x]; }
@@ -1415,7 +1410,7 @@ static int run_bg(pseg_ctx *ctx, const uint8_t *frames, int n, int n_bg_imgs, co
                            (uint8_t *)ctx->bits.p, (uint32_t *)ctx->partials.p);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
-    hipLaunchKernelGGL(k_reduce_partials, dim3(n), dim3(256), 0, ctx->stream, (const uint32_t *)ctx->partials.p, (int)npart,
+    hipLaunchKernelGGL(k_reduce_partials, dim3(n), dim3(1024), 0, ctx->stream, (const uint32_t *)ctx->partials.p, (int)npart,
                        (unsigned long long)P, (unsigned long long *)ctx->fsums.p, (uint8_t *)ctx->valid_dev.p, 1, 0, 4);
     HIPCHK(hipGetLastError());
     return 0;
@@ -1508,7 +1503,7 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
     // maskcnt (8 B) and totals (32 B) are adjacent in the head arena: one clear; no mask = every pixel counts
     HIPCHK(hipMemsetAsync(ctx->maskcnt.p, 0, 40, st));
     if (mask) {
-        hipLaunchKernelGGL(k_mask_count, dim3(256), dim3(256), 0, st, mask, P, (unsigned long long *)ctx->maskcnt.p);
+        hipLaunchKernelGGL(k_mask_count, dim3(1024), dim3(256), 0, st, mask, P, (unsigned long long *)ctx->maskcnt.p);
     }
     hipLaunchKernelGGL(k_runs<false>, dim3(nblocks((size_t)n * H, 4 * RUNS_RPW)), dim3(256), 0, st, S, n * H);
     HIPCHK(hipMemsetAsync(S.framebase + n + 1, 0, 4, st));
@@ -1551,7 +1546,7 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
         hipLaunchKernelGGL(k_bbox, dim3(nblocks(nfg)), dim3(256), 0, st, S, nfg);
         hipLaunchKernelGGL(k_area, dim3(nblocks((size_t)n * H)), dim3(256), 0, st, S, n * H);
     }
-    hipLaunchKernelGGL(k_rank, dim3(n), dim3(256), 0, st, S, min_seg, min_save, ftot3);
+    hipLaunchKernelGGL(k_rank, dim3(n), dim3(1024), 0, st, S, min_seg, min_save, ftot3);
     hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(256), 0, st, (const uint32_t *)(ftot3 + 1), rowbase, n, 3, 1);
     hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(256), 0, st, (const uint32_t *)(ftot3 + 2), savedbase, n, 3, 1);
     HIPCHK(hipGetLastError());
@@ -1758,7 +1753,7 @@ extern "C" int pseg_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t 
                        (uint32_t *)ctx->partials.p);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
-    hipLaunchKernelGGL(k_reduce_partials, dim3(n), dim3(256), 0, ctx->stream, (const uint32_t *)ctx->partials.p, (int)nblk,
+    hipLaunchKernelGGL(k_reduce_partials, dim3(n), dim3(1024), 0, ctx->stream, (const uint32_t *)ctx->partials.p, (int)nblk,
                        (unsigned long long)P, (unsigned long long *)ctx->fsums.p, (uint8_t *)ctx->valid_dev.p, 0, 2, 2);
     HIPCHK(hipGetLastError());
     r = run_detect(ctx, cleaned, raw, mask, n, min_area_to_segment, min_area_to_save, labels, out);
