@@ -481,8 +481,11 @@ __global__ __launch_bounds__(256) void k_mask_count(const uint8_t *__restrict__ 
         uint2 m = *(const uint2 *)(mask + i * 8);
         c += __popc(eq255_4(m.x) & 0x01010101u) + __popc(eq255_4(m.y) & 0x01010101u);
     }
+    __shared__ uint32_t red[4];
     c = wave_sum_u32(c);
-    if ((threadIdx.x & 63) == 0 && c) atomicAdd(cnt, (unsigned long long)c);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0 && (red[0] | red[1] | red[2] | red[3])) atomicAdd(cnt, (unsigned long long)red[0] + red[1] + red[2] + red[3]);
 }
 
 __global__ void k_fill_spans(uint8_t *mask, int H, int W, const int32_t *spans)
@@ -1211,47 +1214,70 @@ __global__ __launch_bounds__(256) void k_crops_sums(SegState S, int n_saved, con
 // points of the row-extremal pixels, then every pixel centre inside or on the hull.  In doubled coordinates
 // R' = 2*row + 1 (+-1), X = 2*col (+-1) the hull's left chain is the lower convex envelope of the profile L(R') and
 // the right chain the upper envelope of U(R'):  odd R' = pixel row r (points (2r, 2c -+ 1)), even R' = between rows
-// r-1 and r ((2r-1, 2c) of either row).  Wave 0 walks the left chain, wave 1 the right chain by a wave-parallel
-// gift-wrapping march: from vertex a, the next vertex is the point of extreme slope among all later points (64 lanes
-// scan + a wave reduction; exact 32-bit cross products: |dX| < 2^15, |dR'| < 2^14 for the heights the LDS admits; ties
-// go to the farthest point).  The vertex list goes to LDS; afterwards every pixel row finds its hull edge by binary
-// search and gets its column bound with one division.  Dynamic LDS: 40 bytes per row of the tallest object served
-// by the launch (the host launches one size class per call so that small objects keep a high occupancy).
-#define HULL_LDS_PER_ROW 40
+// r-1 and r ((2r-1, 2c) of either row).  Wave 0 builds the left chain, wave 1 the right chain, by divide and conquer:
+// every lane takes a contiguous piece of the profile and builds its strict hull with a monotone chain (doubly linked
+// list in LDS); six rounds then merge neighbouring hulls pairwise -- one lane per pair walks the two tangent points
+// outwards from the junction (cost = vertices removed + 1).  Lane 0 reads the final list into a vertex array, and
+// every pixel row finds its hull edge by binary search and gets its column bound with one division.  Exact 32-bit
+// cross products: |dX| < 2^15, |dR'| < 2^14 for the heights the LDS admits; collinear points are dropped.
+// Dynamic LDS: 56 bytes per row of the tallest object served by the launch (the host launches one size class per
+// call so that small objects keep a high occupancy).
+#define HULL_LDS_PER_ROW 56
 template <bool LOWER>
-__device__ __forceinline__ void hull_chain(const int *pv, int np, int *vl, int *bound, int h, int lane)
+__device__ __forceinline__ bool hull_drop(int ra, int va, int rb, int vb, int rc, int vc)   // b is no strict vertex between a and c
 {
-    int a = 0, va = pv[0], nv = 1;
-    if (lane == 0) vl[0] = 0;
-    while (a < np - 1) {
-        int bj = -1, bv = 0;
-#pragma unroll 4
-        for (int j = a + 1 + lane; j < np; j += 64) {
-            const int v = pv[j];
-            const int d = (v - va) * (bj - a) - (bv - va) * (j - a);
-            if (bj < 0 || (LOWER ? d <= 0 : d >= 0)) { bj = j; bv = v; }      // j > bj: a tie goes to the farther point
-        }
-        // wave reduction with DPP moves (same lane pattern as wave_sum63: the full combination ends up in lane 63);
-        // a lane without a DPP source combines with itself, which changes nothing
-#define HULL_STEP(CTRL, RM)                                                                                       \
-        {                                                                                                         \
-            const int oj = __builtin_amdgcn_update_dpp(bj, bj, CTRL, RM, 0xf, false);                             \
-            const int ov = __builtin_amdgcn_update_dpp(bv, bv, CTRL, RM, 0xf, false);                             \
-            const int d = (ov - va) * (bj - a) - (bv - va) * (oj - a);                                            \
-            const bool better = LOWER ? (d < 0 || (d == 0 && oj > bj)) : (d > 0 || (d == 0 && oj > bj));          \
-            if (oj >= 0 && (bj < 0 || better)) { bj = oj; bv = ov; }                                              \
-        }
-        HULL_STEP(0x111, 0xf) HULL_STEP(0x112, 0xf) HULL_STEP(0x114, 0xf) HULL_STEP(0x118, 0xf)
-        HULL_STEP(0x142, 0xa) HULL_STEP(0x143, 0xc)
-#undef HULL_STEP
-        bj = __builtin_amdgcn_readlane(bj, 63); bv = __builtin_amdgcn_readlane(bv, 63);
-        a = bj; va = bv;                                    // the same in every lane
-        if (lane == 0) vl[nv] = a;
-        nv++;
-    }
-    __builtin_amdgcn_wave_barrier();
+    const int d = (rb - ra) * (vc - va) - (vb - va) * (rc - ra);
+    return LOWER ? d <= 0 : d >= 0;
+}
+__device__ __forceinline__ void hull_wave_sync()
+{
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+template <bool LOWER>
+__device__ __forceinline__ void hull_chain(const int *pv, int np, volatile int *nxt, volatile int *prv, int *bound, int h, int lane)
+{
+    const int seg = (np + 63) >> 6;
+    {   // strict hull of the lane's piece [s0, s1)
+        const int s0 = lane * seg, s1 = s0 + seg < np ? s0 + seg : np;
+        if (s0 < np) {
+            int top = s0, vtop = pv[s0];
+            prv[s0] = -1;
+            for (int c = s0 + 1; c < s1; c++) {
+                const int vc = pv[c];
+                for (;;) {
+                    const int p = prv[top];
+                    if (p < 0 || !hull_drop<LOWER>(p, pv[p], top, vtop, c, vc)) break;
+                    top = p; vtop = pv[p];
+                }
+                prv[c] = top; nxt[top] = c; top = c; vtop = vc;
+            }
+            nxt[top] = -1;
+        }
+    }
+    for (int s = 1; s < 64; s <<= 1) {                      // merge the hulls of lanes [l, l+s) and [l+s, l+2s)
+        hull_wave_sync();
+        const int vstart = (lane + s) * seg;
+        if ((lane & (2 * s - 1)) == 0 && vstart < np) {
+            int v = vstart, u = vstart - 1, vu = pv[u], vv = pv[v];
+            for (;;) {
+                bool moved = false;
+                int pu = prv[u];
+                while (pu >= 0 && hull_drop<LOWER>(pu, pv[pu], u, vu, v, vv)) { u = pu; vu = pv[u]; pu = prv[u]; moved = true; }
+                int nv = nxt[v];
+                while (nv >= 0 && hull_drop<LOWER>(u, vu, v, vv, nv, pv[nv])) { v = nv; vv = pv[v]; nv = nxt[v]; moved = true; }
+                if (!moved) break;
+            }
+            nxt[u] = v; prv[v] = u;
+        }
+    }
+    hull_wave_sync();
+    int *vl = (int *)prv;                                   // vertex array over the (now dead) back links: vl[k] sits at or before vertex k
+    int nv = 0;
+    if (lane == 0) for (int i = 0; i >= 0; i = nxt[i]) vl[nv++] = i;
+    nv = __builtin_amdgcn_readfirstlane(nv);
+    hull_wave_sync();
     for (int r = lane; r < h; r += 64) {                    // pixel row r = profile index 2r+1
         const int i = 2 * r + 1;
         int lo = 0, hi = nv - 1;                            // edge k with vl[k] < i <= vl[k+1]
@@ -1273,7 +1299,8 @@ __global__ __launch_bounds__(128) void k_convex(int n_saved, const int32_t *__re
     if (h <= hlo || h > hhi) return;                        // another size class
     const int np = 2 * h + 1;
     int *fl = (int *)hull_smem;                             // first / last column per row; later the two column bounds
-    int *pvl = fl + 2 * hhi, *pvu = pvl + (2 * hhi + 1), *vll = pvu + (2 * hhi + 1), *vlu = vll + (2 * hhi + 1);
+    const int npm = 2 * hhi + 1;
+    int *pvl = fl + 2 * hhi, *pvu = pvl + npm, *nxl = pvu + npm, *prl = nxl + npm, *nxu = prl + npm, *pru = nxu + npm;
     long long *q = sums + (size_t)s * PSEG_NSUMS;
     const int32_t *re = rowext + 2 * row_off[s];
     for (int i = threadIdx.x; i < 2 * h; i += 128) fl[i] = re[i];
@@ -1290,8 +1317,8 @@ __global__ __launch_bounds__(128) void k_convex(int n_saved, const int32_t *__re
         pvl[i] = l; pvu[i] = u;
     }
     __syncthreads();
-    if (threadIdx.x < 64) hull_chain<true>(pvl, np, vll, fl, h, threadIdx.x);
-    else hull_chain<false>(pvu, np, vlu, fl, h, threadIdx.x - 64);
+    if (threadIdx.x < 64) hull_chain<true>(pvl, np, nxl, prl, fl, h, threadIdx.x);
+    else hull_chain<false>(pvu, np, nxu, pru, fl, h, threadIdx.x - 64);
     __syncthreads();
     unsigned long long cnt = 0;
     for (int r = threadIdx.x; r < h; r += 128)
@@ -1621,7 +1648,7 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
         // two size classes: objects up to 256 rows keep 10 KB of LDS per block, the rest is sized by the tallest one
         const int hsmall = hmax < 256 ? hmax : 256;
         const size_t lds_small = (size_t)hsmall * HULL_LDS_PER_ROW + 64, lds_big = (size_t)hmax * HULL_LDS_PER_ROW + 64;
-        if (lds_big > 150 * 1024) return fail(ctx, PSEG_ERR_CAPACITY, "saved object too tall for the convex-hull kernel (limit 3800 rows)");
+        if (lds_big > 150 * 1024) return fail(ctx, PSEG_ERR_CAPACITY, "saved object too tall for the convex-hull kernel (limit 2700 rows)");
         if (lds_big > 48 * 1024)
             HIPCHK(hipFuncSetAttribute((const void *)k_convex, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big));
         hipLaunchKernelGGL(k_convex, dim3(n_saved), dim3(128), lds_small, st, n_saved, (const int32_t *)geo,
