@@ -878,11 +878,11 @@ __global__ __launch_bounds__(256) void k_label_fill(SegState S, const int32_t *_
     if (x0 >= S.W) return;                                   // wave beyond the row end
     const bool in = x < S.W;
     const size_t rowpix = ((size_t)f * S.H + y) * S.W;
-    uint32_t nib = 0;
-    if (in) nib = (uint32_t)(((const uint8_t *)S.bits)[(rowpix + x) >> 3] >> (x & 4)) & 0xfu;
     i32x4_t out = {0, 0, 0, 0};
-    if (__ballot(nib != 0) && S.valid[f]) {
-        const int rs = seg_rowstart(S, f, y), n = seg_rowcount(S, f, y);
+    // the row's run list (L2-resident tables) decides, not the threshold plane: a read stream next to the write stream
+    // costs the stores more than the lookups do
+    const int rs = seg_rowstart(S, f, y), n = seg_rowcount(S, f, y);
+    {
         for (int j0 = 0; j0 < n; j0 += 64) {
             uint32_t rx = 0xffffu; int lab = 0;              // lanes past the row's runs: xs = 65535, xe = 0
             if (j0 + lane < n) { rx = S.run_x[rs + j0 + lane]; lab = runlabel[rs + j0 + lane]; }
