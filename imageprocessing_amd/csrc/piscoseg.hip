@@ -67,7 +67,7 @@ struct pseg_ctx {
     DevBuf rows, saved_row, saved_geo, crop_off, bits_off, maskbits, crops_raw, crops_masked, crops_mask;
     bool have_bits = false;       // threshold plane + masked sums already produced by the bg kernel
     DevBuf bounds, band_off, band_obj, trash;
-    int bounds_n = -1, bounds_chunks = -1;
+    int bounds_n = -1, bounds_emit = -1, bounds_chunks = -1;
     int bg_chunks = 1;            // time chunks of the streaming background kernel (PSEG_BG_CHUNKS)
     bool force_generic = false;   // PSEG_BG_GENERIC=1: use the 12x-read reference kernel (debug / cross-check)
     bool no_bands = false;        // PSEG_NO_BANDS=1: label with the global union-find only (the path of very dense frames)
@@ -1400,14 +1400,23 @@ static int check_batch(pseg_ctx *ctx, int n)
     return 0;
 }
 
-// background kernel launch (+ reduction of the raw sums; masked sums too when fused)
-static int run_bg(pseg_ctx *ctx, const uint8_t *frames, int n, int n_bg_imgs, const uint8_t *mask, int thr, uint8_t *cleaned)
+// background kernel launch (+ reduction of the raw sums; masked sums too when fused).
+// n_avail frames are readable, the first n_emit are emitted.  n_emit == n_avail: a whole reference batch (the last 12
+// frames share one window, bg_correction.py:72).  n_emit < n_avail: the leading part of a batch cut for another GPU;
+// the rest is the forward halo (>= window - 1 frames), so no emitted frame reaches the clamp -- the kernels are simply
+// told the batch is one frame longer than what they may read.
+static int run_bg(pseg_ctx *ctx, const uint8_t *frames, int n_avail, int n_emit, int n_bg_imgs, const uint8_t *mask, int thr,
+                  uint8_t *cleaned)
 {
     int NW = 2 * n_bg_imgs;                                   // bg_correction.py:65
-    if (n_bg_imgs < 1 || 2 * n < NW) return fail(ctx, PSEG_ERR_ARG, "need n >= n_bg_imgs (reference raises IndexError below that)");
+    const bool part = n_emit < n_avail;
+    const int n = n_emit;
+    if (n_bg_imgs < 1 || 2 * n_avail < NW) return fail(ctx, PSEG_ERR_ARG, "need n >= n_bg_imgs (reference raises IndexError below that)");
+    if (part && n_avail - n_emit < NW - 1) return fail(ctx, PSEG_ERR_ARG, "a part of a batch needs a forward halo of 2 * n_bg_imgs - 1 frames");
+    const int n_kernel = part ? n_avail + 1 : n_avail;       // batch length as the kernels see it
     size_t P = ctx->P;
     unsigned nblk = nblocks(P / 8);
-    const bool stream = (NW == 12 && n >= 12 && !ctx->force_generic);
+    const bool stream = (NW == 12 && n_avail >= 12 && !ctx->force_generic);
     unsigned npart = stream ? nblk * 4 : nblk;               // partial sums per frame: per wave / per block
     ENSURE(ctx->bits, (size_t)n * P / 8);
     ENSURE(ctx->partials, (size_t)n * npart * 4 * sizeof(uint32_t));
@@ -1416,24 +1425,25 @@ static int run_bg(pseg_ctx *ctx, const uint8_t *frames, int n, int n_bg_imgs, co
     if (stream) {
         ENSURE(ctx->trash, P + P / 8 + (size_t)npart * 16 + 256);
         chunks = ctx->bg_chunks;
-        if (chunks > n - 12) chunks = n - 12;
+        const int span = part ? n_emit : n_avail - 12;        // chunk starts lie in [0, span)
+        if (chunks > span) chunks = span;
         if (chunks < 1) chunks = 1;
-        if (ctx->bounds_n != n || ctx->bounds_chunks != chunks) {
+        if (ctx->bounds_n != n_avail || ctx->bounds_emit != n_emit || ctx->bounds_chunks != chunks) {
             std::vector<int> bnd(chunks + 1);
-            for (int c = 0; c < chunks; c++) bnd[c] = (int)((long long)c * (n - 12) / chunks);
-            bnd[chunks] = n;
+            for (int c = 0; c < chunks; c++) bnd[c] = (int)((long long)c * span / chunks);
+            bnd[chunks] = n_emit;
             ENSURE(ctx->bounds, (size_t)(chunks + 1) * 4);
             HIPCHK(hipMemcpyAsync(ctx->bounds.p, bnd.data(), (size_t)(chunks + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
             HIPCHK(hipStreamSynchronize(ctx->stream));
-            ctx->bounds_n = n; ctx->bounds_chunks = chunks;
+            ctx->bounds_n = n_avail; ctx->bounds_emit = n_emit; ctx->bounds_chunks = chunks;
         }
     }
     HIPCHK(hipEventRecord(ctx->ev[0], ctx->stream));
     if (stream)
-        hipLaunchKernelGGL(k_bg_stream, dim3(nblk, chunks), dim3(256), 0, ctx->stream, frames, n, P, cleaned, mask, thr,
+        hipLaunchKernelGGL(k_bg_stream, dim3(nblk, chunks), dim3(256), 0, ctx->stream, frames, n_kernel, P, cleaned, mask, thr,
                            (uint8_t *)ctx->bits.p, (uint4 *)ctx->partials.p, (const int *)ctx->bounds.p, (uint8_t *)ctx->trash.p);
     else
-        hipLaunchKernelGGL(k_bg_generic, dim3(nblk, n), dim3(256), 0, ctx->stream, frames, n, NW, P, cleaned, mask, thr,
+        hipLaunchKernelGGL(k_bg_generic, dim3(nblk, n), dim3(256), 0, ctx->stream, frames, n_kernel, NW, P, cleaned, mask, thr,
                            (uint8_t *)ctx->bits.p, (uint32_t *)ctx->partials.p);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
@@ -1483,7 +1493,7 @@ extern "C" int pseg_bgcorrect(pseg_ctx *ctx, const uint8_t *frames, int n, int n
     if (!frames || !cleaned) return fail(ctx, PSEG_ERR_ARG, "null frame pointer");
     ctx->have_bits = false;
     ctx->head_on_host = false;
-    r = run_bg(ctx, frames, n, n_bg_imgs, nullptr, 255, cleaned);
+    r = run_bg(ctx, frames, n, n, n_bg_imgs, nullptr, 255, cleaned);
     if (r) return r;
     r = fetch_raw_stats(ctx, n, mean_std, valid);
     if (r) return r;
@@ -1793,15 +1803,17 @@ extern "C" int pseg_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t 
     return PSEG_OK;
 }
 
-extern "C" int pseg_process(pseg_ctx *ctx, const uint8_t *frames, int n, int n_bg_imgs, const uint8_t *mask, int threshold,
-                            double min_area_to_segment, double min_area_to_save, uint8_t *cleaned, double *mean_std,
-                            uint8_t *valid, int32_t *labels, pseg_table *out)
+extern "C" int pseg_process_part(pseg_ctx *ctx, const uint8_t *frames, int n_avail, int n_emit, int n_bg_imgs, const uint8_t *mask,
+                                 int threshold, double min_area_to_segment, double min_area_to_save, uint8_t *cleaned,
+                                 double *mean_std, uint8_t *valid, int32_t *labels, pseg_table *out)
 {
-    int r = check_batch(ctx, n);
+    int r = check_batch(ctx, n_avail);
     if (r) return r;
     if (!frames || !cleaned) return fail(ctx, PSEG_ERR_ARG, "null frame pointer");
+    if (n_emit < 1 || n_emit > n_avail) return fail(ctx, PSEG_ERR_ARG, "n_emit out of range");
+    const int n = n_emit;
     HIPCHK(hipEventRecord(ctx->ev[6], ctx->stream));
-    r = run_bg(ctx, frames, n, n_bg_imgs, mask, threshold, cleaned);
+    r = run_bg(ctx, frames, n_avail, n_emit, n_bg_imgs, mask, threshold, cleaned);
     if (r) return r;
     r = run_detect(ctx, cleaned, cleaned, mask, n, min_area_to_segment, min_area_to_save, labels, out);
     if (r) return r;
@@ -1813,6 +1825,14 @@ extern "C" int pseg_process(pseg_ctx *ctx, const uint8_t *frames, int n, int n_b
     HIPCHK(hipEventElapsedTime(&ctx->ms[5], ctx->ev[6], ctx->ev[7]));
     ctx->ms[1] = 0;
     return PSEG_OK;
+}
+
+extern "C" int pseg_process(pseg_ctx *ctx, const uint8_t *frames, int n, int n_bg_imgs, const uint8_t *mask, int threshold,
+                            double min_area_to_segment, double min_area_to_save, uint8_t *cleaned, double *mean_std,
+                            uint8_t *valid, int32_t *labels, pseg_table *out)
+{
+    return pseg_process_part(ctx, frames, n, n, n_bg_imgs, mask, threshold, min_area_to_segment, min_area_to_save, cleaned, mean_std,
+                             valid, labels, out);
 }
 
 extern "C" int pseg_fetch_crops(pseg_ctx *ctx, uint8_t *raw, uint8_t *masked, uint8_t *mask)

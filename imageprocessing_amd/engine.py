@@ -163,12 +163,15 @@ class Segmenter:
         return self._table(t, fetch_crops)
 
     def process(self, frames, n_bg_imgs=6, mask=None, threshold=10, min_area_to_segment=10.0, min_area_to_save=400.0,
-                cleaned=None, labels=None, fetch_crops=False, want_table=True):
+                cleaned=None, labels=None, fetch_crops=False, want_table=True, n_emit=None):
+        """Fused hot path over one batch.  ``n_emit`` < len(frames): ``frames`` is the leading part of a batch plus its
+        forward halo (sharding.plan_ranges); only the first n_emit frames are processed and returned."""
         import torch
-        n = frames.shape[0]
+        n_avail = frames.shape[0]
+        n = n_avail if n_emit is None else int(n_emit)
         self._check_frames(frames)
         if cleaned is None:
-            cleaned = torch.empty_like(frames)
+            cleaned = torch.empty((n,) + tuple(frames.shape[1:]), dtype=torch.uint8, device=frames.device)
         self._check_frames(cleaned, n)
         if labels is not None:
             self._check_frames(labels, n, torch.int32)
@@ -176,9 +179,9 @@ class Segmenter:
         valid = np.zeros(n, np.uint8)
         t = _lib.Table()
         torch.cuda.current_stream(frames.device).synchronize()
-        self._chk(self.L.pseg_process(self.h, frames.data_ptr(), n, n_bg_imgs, None if mask is None else mask.data_ptr(),
-                                      int(threshold), float(min_area_to_segment), float(min_area_to_save), cleaned.data_ptr(),
-                                      ms.ctypes.data, valid.ctypes.data, None if labels is None else labels.data_ptr(), C.byref(t)))
+        self._chk(self.L.pseg_process_part(self.h, frames.data_ptr(), n_avail, n, n_bg_imgs, None if mask is None else mask.data_ptr(),
+                                           int(threshold), float(min_area_to_segment), float(min_area_to_save), cleaned.data_ptr(),
+                                           ms.ctypes.data, valid.ctypes.data, None if labels is None else labels.data_ptr(), C.byref(t)))
         tab = self._table(t, fetch_crops) if want_table else None
         return cleaned, ms, valid, tab
 

@@ -35,6 +35,42 @@ def assign_batches(batches, world_size):
     return out
 
 
+def plan_ranges(n_files, world_size, batch_size=200, window=12):
+    """Contiguous frame ranges per rank: the stack is cut at k * n_files / world_size, every cut moved so
+    that no part begins inside the last ``window`` frames of a reference batch (those frames share one background window,
+    bg_correction.py:72, and stay with the part that ends the batch).  Returns, per rank, a list of parts
+    ``dict(start, n_emit, n_avail)``: global index of the part's first frame, frames to process, frames to load
+    (n_emit plus a forward halo of window - 1 frames unless the part ends its batch) -- the arguments of
+    ``pseg_process_part`` / ``Segmenter.process(..., n_emit=)``.  No pixel crosses GPUs."""
+    batches = batches_of(n_files, batch_size)
+
+    def snap(cut):
+        for bs, bl in batches:
+            if bs < cut < bs + bl:
+                r = cut - bs
+                if r > bl - window:                      # inside the tail: move to whichever end of the tail is nearer
+                    r = bl - window if (r - (bl - window)) <= (bl - r) and bl - window > 0 else bl
+                return bs + r
+        return cut
+
+    cuts = [0] + [snap(k * n_files // world_size) for k in range(1, world_size)] + [n_files]
+    cuts = [max(c, p) for c, p in zip(cuts, [0] + cuts[:-1])]          # keep them monotone
+    for i in range(1, len(cuts)):
+        cuts[i] = max(cuts[i], cuts[i - 1])
+    out = []
+    for k in range(world_size):
+        g0, g1 = cuts[k], cuts[k + 1]
+        parts = []
+        for bs, bl in batches:
+            lo, hi = max(g0, bs), min(g1, bs + bl)
+            if lo >= hi:
+                continue
+            ends_batch = hi == bs + bl
+            parts.append(dict(start=lo, n_emit=hi - lo, n_avail=(hi - lo) if ends_batch else (hi - lo) + window - 1))
+        out.append(parts)
+    return out
+
+
 TABLE_FIELDS = ["frame_row_offset", "frame_n_contours", "frame_valid", "frame_mean", "frame_std", "frame", "c", "label",
                 "area", "x", "y", "w", "h", "saved", "props", "saved_row", "crop_offset", "sums"]
 

@@ -10,7 +10,8 @@
  * Conventions: every function returns 0 on success and a negative code on failure (never
  * aborts; the reference's convention is "print and carry on").  pseg_last_error() gives the text.
  * Pointers marked [dev] are device pointers on the context's GPU (e.g. torch.Tensor.data_ptr()),
- * [host] are host pointers.  Frames are row-major uint8 [n][H][W]; W must be a multiple of 64.
+ * [host] are host pointers.  Frames are row-major uint8 [n][H][W]; W % 64 == 0, W <= 8192, H <= 65535,
+ * n <= max_frames <= 65535; a saved object may be at most 2700 rows tall (convex-hull kernel).
  * A context is not re-entrant: one call at a time per context (one context per Python thread/GPU).
  */
 #ifndef PISCOSEG_H
@@ -99,6 +100,17 @@ int pseg_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw, const
 int pseg_process(pseg_ctx *ctx, const uint8_t *frames, int n, int n_bg_imgs, const uint8_t *mask,
                  int threshold, double min_area_to_segment, double min_area_to_save,
                  uint8_t *cleaned, double *mean_std, uint8_t *valid, int32_t *labels, pseg_table *out);
+
+/* The leading part of a reference batch, for stacks cut into frame ranges over several GPUs (the
+ * reference's unit is the whole 200-frame batch, segmenter.py:209-213).  frames [dev] u8[n_avail][H][W] holds the
+ * part's frames followed by its forward halo; the first n_emit frames are processed, each with the window
+ * frames[i .. i + 2*n_bg_imgs) (bg_correction.py:72 without the clamp), so n_avail - n_emit >= 2*n_bg_imgs - 1 when
+ * n_emit < n_avail.  n_emit == n_avail is pseg_process (the part that ends the batch: the last 2*n_bg_imgs frames share
+ * one window).  cleaned / labels / mean_std / valid / out cover the n_emit frames.  A part must not begin inside the
+ * last 2*n_bg_imgs frames of its batch (imageprocessing_amd.sharding.plan_ranges snaps the cuts). */
+int pseg_process_part(pseg_ctx *ctx, const uint8_t *frames, int n_avail, int n_emit, int n_bg_imgs,
+                      const uint8_t *mask, int threshold, double min_area_to_segment, double min_area_to_save,
+                      uint8_t *cleaned, double *mean_std, uint8_t *valid, int32_t *labels, pseg_table *out);
 
 /* Copy the three packed crop planes of the last detection to host buffers of crop_bytes each
  * (any may be NULL).  Replaces the arrays handed to cv.imwrite (detection.py:251-253). */

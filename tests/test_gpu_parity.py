@@ -170,3 +170,36 @@ def test_detect_edge_cases(gpu_seg_factory):
     empty = np.full((3, H, W), 255, np.uint8)
     tab = seg.detect(torch.from_numpy(empty).cuda(), fetch_crops=True)
     assert tab.n_rows == 0 and tab.crop_bytes == 0 and len(tab.saved_row) == 0
+
+
+def test_frame_range_parts_equal_whole_batch(gpu_seg_factory):
+    """A batch cut into frame ranges (pseg_process_part with forward halos) gives byte-identical
+    cleaned frames, label maps and merged tables to the batch processed whole."""
+    import torch
+    from imageprocessing_amd import sharding
+    H, W, n = 128, 192, 61
+    seg = gpu_seg_factory(H, W)
+    stack, _, _ = _stack(n, H, W, 9, per_frame=14, dmin=15, dmax=300)
+    stack[20] = 90                                        # corrupt frame in the middle part
+    mask = torch.from_numpy(helpers.make_disk(H, W, 60)).cuda()
+    dev = torch.from_numpy(stack).cuda()
+    labels = torch.empty((n, H, W), dtype=torch.int32, device="cuda")
+    cleaned, ms, valid, whole = seg.process(dev, mask=mask, labels=labels, min_area_to_save=100.0)
+    ref = sharding.merge_tables([sharding.unpack_table(sharding.pack_table(whole))])
+    for world in (2, 3, 5):
+        blobs = []
+        for parts in sharding.plan_ranges(n, world):
+            for p in parts:
+                s, ne, na = p["start"], p["n_emit"], p["n_avail"]
+                lab = torch.empty((ne, H, W), dtype=torch.int32, device="cuda")
+                c, m, v, tab = seg.process(dev[s:s + na], mask=mask, labels=lab, min_area_to_save=100.0, n_emit=ne)
+                assert torch.equal(c[v.astype(bool)], cleaned[s:s + ne][v.astype(bool)])
+                assert torch.equal(lab, labels[s:s + ne])
+                np.testing.assert_array_equal(m, ms[s:s + ne])
+                np.testing.assert_array_equal(v, valid[s:s + ne])
+                blobs.append(sharding.pack_table(tab, frame_base=s))
+        got = sharding.merge_tables([sharding.unpack_table(b) for b in blobs])
+        for k in ref:
+            if k == "shard_of_saved":
+                continue
+            np.testing.assert_array_equal(got[k], ref[k], err_msg=f"world {world}: {k}")

@@ -110,3 +110,32 @@ def test_gather_tables_gloo_world2():
     r1 = [r for r in res if not isinstance(r, tuple)][0]
     rows0 = len(fake_table(4, np.random.default_rng(0)).frame)
     assert r0[0] == 2 and r0[1] == rows0 + r1
+
+
+@pytest.mark.parametrize("n_files,world", [(2000, 8), (10000, 8), (450, 3), (200, 2), (30, 4), (1999, 7), (13, 2), (5, 3)])
+def test_plan_ranges_covers_every_frame_once_with_local_windows(n_files, world):
+    """Every frame is emitted by exactly one part, and the background window the reference gives it
+    (bg_correction.py:72, inside its own batch) lies inside the frames that part loads."""
+    window = 12
+    plan = sharding.plan_ranges(n_files, world, window=window)
+    assert len(plan) == world
+    batches = sharding.batches_of(n_files)
+    owner = np.full(n_files, -1)
+    for rank, parts in enumerate(plan):
+        for p in parts:
+            s, ne, na = p["start"], p["n_emit"], p["n_avail"]
+            assert ne >= 1 and na >= ne
+            bs, bl = next((bs, bl) for bs, bl in batches if bs <= s < bs + bl)
+            assert s + na <= bs + bl, "a part never reads past its batch"
+            assert (owner[s:s + ne] == -1).all()
+            owner[s:s + ne] = rank
+            for g in range(s, s + ne):
+                i = g - bs                                   # index inside the reference batch
+                if bl >= window:
+                    start = i if i + window < bl else bl - window
+                    assert s - bs <= start and start + window <= s - bs + na
+                    il = g - s                               # what pseg_process_part computes locally
+                    local = il if (na > ne or il + window < na) else na - window
+                    assert local + (s - bs) == start
+    assert (owner >= 0).all()
+    assert (np.diff(owner) >= 0).all(), "ranks own contiguous, ordered ranges"
