@@ -10,7 +10,7 @@ rank 0 over RCCL inside the timed region.
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel group, timed with HIP events
 on the library's stream; `cpu_baseline` is the CPU oracle (a port of the reference's arithmetic) on
-a bounded sample of the same frames on the host cores of this box.
+one batch of the same frames, run with the reference's process topology on the host cores of this box.
 """
 import argparse
 import json
@@ -39,12 +39,14 @@ GROUP_NAMES = {0: "bg_correct", 2: "sparse_labelling", 3: "label_map", 4: "crops
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--batches", type=int, default=10, help="distinct 200-frame batches resident per rank")
     ap.add_argument("--workload", default="pisco", choices=["pisco", "uvp5_dense"])
     ap.add_argument("--no-labels", action="store_true", help="streamed mode: label map not materialised (config #5)")
-    ap.add_argument("--cpu-frames", type=int, default=13, help="frames of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=200, help="frames of the CPU-baseline sample (0 = skip); 200 = one reference batch")
+    ap.add_argument("--cpu-procs", default="3,8", help="background-correction,detection processes of the CPU baseline "
+                    "(reference topology: bg_correction.py:120 / segmenter.py:252); '1,1' = single core, in-process")
     ap.add_argument("--streams", type=int, default=2, help="contexts (own HIP stream + host thread each) that alternate batches")
     args = ap.parse_args()
 
@@ -172,17 +174,28 @@ def main():
     }
 
     if rank == 0 and world == 1 and args.cpu_frames >= 12:
-        from tests import helpers          # the oracle is the timed CPU port here, never the product path
-        nf = args.cpu_frames
+        # the oracle is the timed CPU port here, never the product path
+        nf = min(args.cpu_frames, BATCH)
         sample = stacks[0][:nf].cpu().numpy()
         hmask = mask.cpu().numpy()
-        c0 = time.perf_counter()
-        items = helpers.oracle_bgcorrect(sample)
-        helpers.oracle_detect(items, hmask, want_labels=False)
-        ct = time.perf_counter() - c0
-        out["cpu_baseline"] = {"value": round(nf / ct, 3), "unit": "frames/s", "cores": 1, "kind": "port",
-                               "sample": f"first {nf} frames of batch 0 treated as one batch (window 12), NumPy + C oracle, "
-                                         f"single thread, no PNG/CSV writes, host has {os.cpu_count()} logical CPUs"}
+        pb, pd = (int(v) for v in args.cpu_procs.split(","))
+        if pb == 1 and pd == 1:
+            from tests import helpers
+            c0 = time.perf_counter()
+            items = helpers.oracle_bgcorrect(sample)
+            helpers.oracle_detect(items, hmask, want_labels=False)
+            ct = time.perf_counter() - c0
+            cores, how = 1, "single thread, in-process"
+        else:
+            from oracle import cpu_pool
+            r = cpu_pool.run(sample, hmask, pb, pd)
+            ct = r["seconds_bg"] + r["seconds_det"]
+            cores = max(pb, pd)
+            how = (f"reference topology: background correction in {pb} processes ({r['seconds_bg']:.2f} s), then detection in "
+                   f"{pd} processes ({r['seconds_det']:.2f} s), frames through /dev/shm")
+        out["cpu_baseline"] = {"value": round(nf / ct, 3), "unit": "frames/s", "cores": cores, "kind": "port",
+                               "sample": f"first {nf} frames of batch 0 as one batch (window 12), NumPy + C oracle, {how}, "
+                                         f"no PNG/CSV writes, host has {os.cpu_count()} logical CPUs"}
     if rank == 0:
         print(json.dumps(out))
     for sg in segs:
