@@ -24,8 +24,9 @@ class Table(C.Structure):
         ("row_frame", C.POINTER(C.c_int32)), ("row_c", C.POINTER(C.c_int32)), ("row_label", C.POINTER(C.c_int32)),
         ("row_area", C.POINTER(C.c_double)),
         ("row_x", C.POINTER(C.c_int32)), ("row_y", C.POINTER(C.c_int32)), ("row_w", C.POINTER(C.c_int32)), ("row_h", C.POINTER(C.c_int32)),
-        ("row_saved", C.POINTER(C.c_uint8)), ("row_props", C.POINTER(C.c_double)),
-        ("saved_row", C.POINTER(C.c_int32)), ("crop_offset", C.POINTER(C.c_int64)), ("sums", C.POINTER(C.c_int64)),
+        ("row_saved", C.POINTER(C.c_uint8)),
+        ("saved_row", C.POINTER(C.c_int32)), ("crop_offset", C.POINTER(C.c_int64)),
+        ("saved_props", C.POINTER(C.c_double)), ("sums", C.POINTER(C.c_int64)),
         ("crops_raw_dev", C.c_void_p), ("crops_masked_dev", C.c_void_p), ("crops_mask_dev", C.c_void_p),
     ]
 

@@ -1703,17 +1703,16 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
     }
     double *h_area = ctx->h_area.as<double>(hr);
     uint8_t *h_s8 = ctx->h_saved8.as<uint8_t>(hr);
-    double *h_props = ctx->h_props.as<double>(hr * PSEG_NPROPS);
+    double *h_props = ctx->h_props.as<double>(hs * PSEG_NPROPS);       // [n_saved][32]
     for (int i = 0; i < n_rows; i++) {
         h_area[i] = 0.5 * (double)hrows[3 * hr + i];
         h_s8[i] = (uint8_t)hrows[8 * hr + i];
-        for (int k = 0; k < PSEG_NPROPS; k++) h_props[(size_t)i * PSEG_NPROPS + k] = NAN;
     }
     for (int s = 0; s < n_saved; s++) {
         int i = h_saved_row[s];
         int64_t *q = h_sums + (size_t)s * PSEG_NSUMS;
         q[9] = q[0];                                         // filled area (see FA below)
-        double *p = h_props + (size_t)i * PSEG_NPROPS;
+        double *p = h_props + (size_t)s * PSEG_NPROPS;
         const double w = hrows[6 * hr + i], h = hrows[7 * hr + i];
         const double N = (double)q[0];
         const double cr = q[1] / N, cc = q[2] / N;
@@ -1761,7 +1760,7 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
         out->frame_mean = h_mean; out->frame_std = h_std;
         out->row_frame = hrows; out->row_c = hrows + hr; out->row_label = hrows + 2 * hr; out->row_area = h_area;
         out->row_x = hrows + 4 * hr; out->row_y = hrows + 5 * hr; out->row_w = hrows + 6 * hr; out->row_h = hrows + 7 * hr;
-        out->row_saved = h_s8; out->row_props = h_props; out->saved_row = h_saved_row; out->crop_offset = h_crop_off;
+        out->row_saved = h_s8; out->saved_props = h_props; out->saved_row = h_saved_row; out->crop_offset = h_crop_off;
         out->sums = h_sums;
         out->crops_raw_dev = (const uint8_t *)ctx->crops_raw.p; out->crops_masked_dev = (const uint8_t *)ctx->crops_masked.p;
         out->crops_mask_dev = (const uint8_t *)ctx->crops_mask.p;

@@ -57,13 +57,17 @@ def rows_of_frame(tab, f, fn, mean_raw):
     reference's value types (ints for saved boxes, centre floats for unsaved ones, nan padding)."""
     rows = []
     a, b = int(tab.frame_row_offset[f]), int(tab.frame_row_offset[f + 1])
+    s_of_row = getattr(tab, "_s_of_row", None)
+    if s_of_row is None:
+        s_of_row = {int(r): s for s, r in enumerate(tab.saved_row)}
+        tab._s_of_row = s_of_row
     for i in range(a, b):
         c = int(tab.c[i])
         name = f"{fn[:-4]}_{c}.png"
         x, y, w, h = int(tab.x[i]), int(tab.y[i]), int(tab.w[i]), int(tab.h[i])
         head = [c, name, mean_raw[0], mean_raw[1], float(tab.frame_mean[f]), float(tab.frame_std[f]), float(tab.area[i])]
         if tab.saved[i]:
-            props = [int(v) if k in _INT_PROPS else float(v) for k, v in zip(PROP_KEYS, tab.props[i])]
+            props = [int(v) if k in _INT_PROPS else float(v) for k, v in zip(PROP_KEYS, tab.saved_props[s_of_row[i]])]
             rows.append(head + [x, y, w, h, 1] + props)
         else:
             rows.append(head + [x + w / 2, y + h / 2, float(w), float(h), 0] + [np.nan] * 32)

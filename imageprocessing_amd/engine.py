@@ -49,7 +49,7 @@ class ObjectTable:
     w: np.ndarray
     h: np.ndarray
     saved: np.ndarray
-    props: np.ndarray
+    saved_props: np.ndarray                       # [n_saved, 32] region properties of saved object s
     saved_row: np.ndarray
     crop_offset: np.ndarray
     sums: np.ndarray
@@ -59,6 +59,13 @@ class ObjectTable:
     @property
     def n_rows(self):
         return len(self.frame)
+
+    @property
+    def props(self):
+        """[n_rows, 32]: the reference's columns 13..44, nan for unsaved rows (detection.py:269-271)."""
+        full = np.full((self.n_rows, len(PROP_KEYS)), np.nan)
+        full[self.saved_row] = self.saved_props
+        return full
 
     def crop(self, s, plane="masked"):
         """h x w uint8 crop of saved object s from a fetched plane."""
@@ -135,7 +142,7 @@ class Segmenter:
             frame=_np(t.row_frame, nr, np.int32), c=_np(t.row_c, nr, np.int32), label=_np(t.row_label, nr, np.int32),
             area=_np(t.row_area, nr, np.float64), x=_np(t.row_x, nr, np.int32), y=_np(t.row_y, nr, np.int32),
             w=_np(t.row_w, nr, np.int32), h=_np(t.row_h, nr, np.int32), saved=_np(t.row_saved, nr, np.uint8),
-            props=_np(t.row_props, nr * _lib.NPROPS, np.float64).reshape(nr, _lib.NPROPS),
+            saved_props=_np(t.saved_props, ns * _lib.NPROPS, np.float64).reshape(ns, _lib.NPROPS),
             saved_row=_np(t.saved_row, ns, np.int32), crop_offset=_np(t.crop_offset, ns + 1, np.int64),
             sums=_np(t.sums, ns * _lib.NSUMS, np.int64).reshape(ns, _lib.NSUMS), crop_bytes=int(t.crop_bytes))
         if fetch_crops:

@@ -72,7 +72,7 @@ def plan_ranges(n_files, world_size, batch_size=200, window=12):
 
 
 TABLE_FIELDS = ["frame_row_offset", "frame_n_contours", "frame_valid", "frame_mean", "frame_std", "frame", "c", "label",
-                "area", "x", "y", "w", "h", "saved", "props", "saved_row", "crop_offset", "sums"]
+                "area", "x", "y", "w", "h", "saved", "saved_props", "saved_row", "crop_offset", "sums"]
 
 
 def pack_table(tab, frame_base=0):
@@ -96,7 +96,7 @@ def merge_tables(parts):
     parts = sorted(parts, key=lambda p: int(p["meta"][1]))
     out = {}
     for k in ("frame_n_contours", "frame_valid", "frame_mean", "frame_std", "frame", "c", "label", "area", "x", "y", "w",
-              "h", "saved", "props", "sums"):
+              "h", "saved", "saved_props", "sums"):
         out[k] = np.concatenate([p[k] for p in parts])
     rows = np.cumsum([0] + [len(p["frame"]) for p in parts])
     crops = np.cumsum([0] + [int(p["meta"][2]) for p in parts])

@@ -53,10 +53,11 @@ typedef struct pseg_table {
     const double *row_area;           /* [n_rows] cv.contourArea (CSV col 7)                        */
     const int32_t *row_x, *row_y, *row_w, *row_h; /* cv.boundingRect, top-left + size              */
     const uint8_t *row_saved;         /* [n_rows] 1 if contourArea > min_area_to_save (CSV col 12)  */
-    const double *row_props;          /* [n_rows*32] regionprops columns, NaN for unsaved rows      */
     const int32_t *saved_row;         /* [n_saved] row index of saved object s                      */
     const int64_t *crop_offset;       /* [n_saved+1] byte offset of object s in each crop plane     */
-    const int64_t *sums;              /* [n_saved*PSEG_NSUMS] exact integer sums behind row_props   */
+    const double *saved_props;        /* [n_saved*32] regionprops columns of saved object s (the reference writes
+                                         32 x nan for unsaved rows, detection.py:269-271)              */
+    const int64_t *sums;              /* [n_saved*PSEG_NSUMS] exact integer sums behind saved_props */
     /* packed crops on the device, row-major h*w per saved object at crop_offset[s]:              */
     const uint8_t *crops_raw_dev;     /* raw_bg_corr[y:y+h, x:x+w]          (Crops/,  detection.py:244) */
     const uint8_t *crops_masked_dev;  /* where(c_mask==255, crop, 255)      (Deconv_crops/, :247)      */

@@ -35,6 +35,7 @@ def compare_table(tab, dets, H, W, labels=None, check_props=True, rtol=1e-5):
     columns / crops and float columns within rtol."""
     n = len(dets)
     assert tab.n_frames == n
+    props_all = tab.props                                   # [n_rows, 32], nan for unsaved rows
     for f, d in enumerate(dets):
         a, b = tab.frame_row_offset[f], tab.frame_row_offset[f + 1]
         if d["corrupt"]:
@@ -58,7 +59,7 @@ def compare_table(tab, dets, H, W, labels=None, check_props=True, rtol=1e-5):
                 assert (tab.x[i], tab.y[i], tab.w[i], tab.h[i]) == tuple(row[7:11]), f"frame {f} obj {k}: bbox"
             else:
                 assert (tab.x[i] + tab.w[i] / 2, tab.y[i] + tab.h[i] / 2, tab.w[i], tab.h[i]) == tuple(row[7:11])
-                assert np.isnan(tab.props[i]).all()
+                assert np.isnan(props_all[i]).all()
         # crops + props of the saved objects
         s_of_row = {int(r): s for s, r in enumerate(tab.saved_row)}
         for k, row in enumerate(rows):
@@ -73,7 +74,7 @@ def compare_table(tab, dets, H, W, labels=None, check_props=True, rtol=1e-5):
                 assert np.array_equal(tab.crop(s, "raw"), raw), f"frame {f} obj {k}: raw crop"
             if check_props:
                 want = np.array([float(v) for v in row[12:]])
-                got = tab.props[i]
+                got = props_all[i]
                 for j, key in enumerate(PROP_KEYS):
                     if np.isnan(got[j]) and key in check_props_pending():
                         continue

@@ -48,9 +48,9 @@ def fake_table(n_frames, rng, crop_bytes_per_saved=50):
     t.area = rng.random(nr) * 1000
     t.x, t.y, t.w, t.h = (rng.integers(0, 100, nr).astype(np.int32) for _ in range(4))
     t.saved = (t.area > 400).astype(np.uint8)
-    t.props = rng.random((nr, 32))
     t.saved_row = np.nonzero(t.saved)[0].astype(np.int32)
     ns = len(t.saved_row)
+    t.saved_props = rng.random((ns, 32))
     t.crop_offset = (np.arange(ns + 1) * crop_bytes_per_saved).astype(np.int64)
     t.sums = rng.integers(0, 1000, (ns, 24)).astype(np.int64)
     t.crop_bytes = ns * crop_bytes_per_saved
