@@ -601,8 +601,8 @@ __global__ void k_bg_union(SegState S, int nfg, int nt, int bandh) { size_t g = 
 // frame-connected background (smallest background index of the frame, seg_b0) is the virtual node -1 here.  Also does
 // the work of k_init for the band.  Used when no band of the batch has more than BAND_CAP runs (k_scan_rows reports
 // the maximum); otherwise the host takes the global path.
-#define BAND_H 128
-#define BAND_CAP 2048
+#define BAND_H 64
+#define BAND_CAP 1024
 __device__ __forceinline__ int lds_find(int *par, int a)
 {
     if (a < 0) return -1;
@@ -723,7 +723,7 @@ __global__ __launch_bounds__(256) void k_bbox(SegState S, int nfg)
     for (int i = threadIdx.x; i < 512; i += 256)
         if (keys[i] >= 0) bbox_flush(S, keys[i], vminx[i], vmaxx[i], vmaxy[i]);
 }
-__global__ void k_area(SegState S, int nfy) { size_t g = GTID; if (g < (size_t)nfy) area_body(S, (int)g); }
+__global__ void k_area(SegState S, int nfg) { size_t g = GTID; if (g < (size_t)nfg) area_body(S, (int)g); }
 
 // exclusive scan of rowcnt inside each frame (block per frame); ftot[f] = runs in frame f
 __global__ __launch_bounds__(256) void k_scan_rows(SegState S, uint32_t *ftot, uint32_t *bandmax)
@@ -1581,7 +1581,7 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
     if (nfg > 0) {
         hipLaunchKernelGGL(k_resolve_ext, dim3(nblocks(nfg)), dim3(256), 0, st, S, nfg);
         hipLaunchKernelGGL(k_bbox, dim3(nblocks(nfg)), dim3(256), 0, st, S, nfg);
-        hipLaunchKernelGGL(k_area, dim3(nblocks((size_t)n * H)), dim3(256), 0, st, S, n * H);
+        hipLaunchKernelGGL(k_area, dim3(nblocks(nfg)), dim3(256), 0, st, S, nfg);
     }
     hipLaunchKernelGGL(k_rank, dim3(n), dim3(1024), 0, st, S, min_seg, min_save, ftot3);
     hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(256), 0, st, (const uint32_t *)(ftot3 + 1), rowbase, n, 3, 1);

@@ -239,30 +239,43 @@ PSEG_HD bool span_next(const SegState &S, SpanIter &it, int &id, int &xs, int &x
     return false;
 }
 
-// ---- 7. contour area from 2x2 quads of the filled object (thread per row pair) ----------------
-PSEG_HD void area_body(const SegState &S, int fy)
+// ---- 7. contour area from 2x2 quads of the filled object ---------------------------------------
+// A span = maximal stretch of a row that lies in the hole-filled region of one object: runs of the object (and of
+// components nested in it) joined by the gaps it fills; a span begins and ends with a run (a filled gap always has a run
+// of the same object on either side).  Thread per run: the run that begins a span walks to the span's end, finds the
+// spans of the same object in the next row that overlap it and adds, per pair [a,b] x [c,d],
+//   2 * #(columns x with x, x+1 in both)  +  #(2x2 quads with exactly three pixels set)   to area2[object].
+PSEG_HD void area_body(const SegState &S, int r)
 {
-    int f = fy / S.H, y = fy % S.H;
+    const int id = S.ext[r];
+    const int y = (int)(S.run_fy[r] & 0xffffu), f = (int)(S.run_fy[r] >> 16);
     if (y + 1 >= S.H) return;
-    if (seg_rowcount(S, f, y) == 0 || seg_rowcount(S, f, y + 1) == 0) return;
-    SpanIter ia, ib;
-    span_begin(S, ia, f, y);
-    span_begin(S, ib, f, y + 1);
-    int ida, a, b, idb, c, d;
-    bool ha = span_next(S, ia, ida, a, b), hb = span_next(S, ib, idb, c, d);
-    while (ha && hb) {
-        if (b < c) { ha = span_next(S, ia, ida, a, b); continue; }
-        if (d < a) { hb = span_next(S, ib, idb, c, d); continue; }
-        if (ida == idb) {
-            int lo = a > c ? a : c, hi = b < d ? b : d;
-            int q4 = hi - lo;                            // columns x with x, x+1 in both spans
-            int q3 = (a <= c - 1 && c <= b) + (a <= d && d + 1 <= b) + (c <= a - 1 && a <= d) + (c <= b && b + 1 <= d);
-            int add = 2 * (q4 > 0 ? q4 : 0) + q3;
-            if (add) PSEG_ATOMIC_ADD(&S.area2[ida], add);
+    const int rs = seg_rowstart(S, f, y), re = seg_rowstart(S, f, y + 1), ne = re + seg_rowcount(S, f, y + 1);
+    if (re == ne) return;                                // the next row has no runs
+    if (r > rs && S.gapl[r] == id) return;               // not the first run of its span
+    const int a = run_xs(S, r);
+    int e = r;
+    while (e + 1 < re && S.gapl[e + 1] == id) e++;
+    const int b = run_xe(S, e);
+    int lo = re, hi = ne;                                // first run q of the next row with xe >= a
+    while (lo < hi) { int m = (lo + hi) >> 1; if (run_xe(S, m) >= a) hi = m; else lo = m + 1; }
+    int q = lo;
+    while (q > re && S.gapl[q] == S.ext[q]) q--;         // that run may sit inside a span that began further left
+    int add = 0;
+    while (q < ne) {
+        const int qid = S.ext[q];
+        const int c = run_xs(S, q);
+        if (c > b) break;
+        int qe = q;
+        while (qe + 1 < ne && S.gapl[qe + 1] == qid) qe++;
+        const int d = run_xe(S, qe);
+        if (qid == id && d >= a) {
+            const int l = a > c ? a : c, h = b < d ? b : d;
+            add += 2 * (h - l) + (a <= c - 1) + (d + 1 <= b) + (c <= a - 1) + (b + 1 <= d);
         }
-        if (b < d) ha = span_next(S, ia, ida, a, b);
-        else hb = span_next(S, ib, idb, c, d);
+        q = qe + 1;
     }
+    if (add) PSEG_ATOMIC_ADD(&S.area2[id], add);
 }
 
 // classification of a run as the root of an external component

@@ -75,7 +75,7 @@ def test_process_parity(gpu_seg_factory, H, W, n, seed, kw):
 @pytest.mark.parametrize("H,no_bands", [(64, "0"), (64, "1"), (300, "0")])
 def test_detect_noise_images(monkeypatch, H, no_bands):
     """Dense random binary images: stresses nesting, pinches, spurs and the cumulative mask.  Labelling runs once
-    through the LDS bands + boundary merge (H = 300: three bands, the last one short) and once through the global
+    through the LDS bands + boundary merge (H = 300: five bands, the last one short) and once through the global
     union-find alone (the path of frames too dense for the bands)."""
     import torch
     from imageprocessing_amd.engine import Segmenter
