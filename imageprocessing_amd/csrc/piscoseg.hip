@@ -525,16 +525,18 @@ template <bool FILL>
 __global__ __launch_bounds__(256) void k_runs(SegState S, int nrows)
 {
     const int lane = threadIdx.x & 63;
-    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RUNS_RPW;
+    // the wave index is uniform: keeping it in a scalar register moves all per-row index arithmetic off the VALU
+    const int row0 = (blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) * RUNS_RPW;
     if (row0 >= nrows) return;
     unsigned long long todo;
+    int startv = 0;                                       // lane i < RUNS_RPW: index of the first run of row row0 + i
     {
         const int row = row0 + lane;
         bool want = lane < RUNS_RPW && row < nrows;
         if (want) {
             const int f = row / S.H;
             if (!S.valid[f]) { want = false; if (!FILL) S.rowcnt[row] = 0; }
-            else if (FILL) want = seg_rowcount(S, f, row - f * S.H) != 0;
+            else if (FILL) { want = seg_rowcount(S, f, row - f * S.H) != 0; startv = seg_rowstart(S, f, row - f * S.H); }
         }
         todo = __ballot(want);
     }
@@ -553,7 +555,7 @@ __global__ __launch_bounds__(256) void k_runs(SegState S, int nrows)
         const int f = row / S.H, y = row - f * S.H;
         const uint64_t *rb = S.bits + (size_t)row * S.WW;
         uint32_t total = 0, carry = 0;
-        const int base = FILL ? seg_rowstart(S, f, y) : 0;
+        const int base = FILL ? __builtin_amdgcn_readlane(startv, i) : 0;
         for (int w0 = 0; w0 < S.WW; w0 += 64) {
             const int w = w0 + lane;
             const uint64_t v = small ? pre[i] : (w < S.WW ? rb[w] : 0);
@@ -564,6 +566,20 @@ __global__ __launch_bounds__(256) void k_runs(SegState S, int nrows)
             uint32_t c = (uint32_t)__popcll(st);
             uint32_t incl = wave_scan_incl(c);
             if (FILL) {
+                // ones that continue a run from bit 0 of this word on, over the following words of the chunk: suffix
+                // doubling over the lanes (bit 31 = "every word so far is full"); only when some word ends set
+                uint32_t ext = 0;
+                if (__ballot(top != 0)) {
+                    ext = (v == ~0ull) ? (0x80000000u | 64u) : (uint32_t)(__ffsll((unsigned long long)~v) - 1);
+#pragma unroll
+                    for (int d = 1; d < 64; d <<= 1) {
+                        uint32_t o = __shfl_down(ext, d, 64);
+                        if (lane + d > 63) o = (w0 + 64 < S.WW) ? 0x80000000u : 0u;   // beyond the chunk: unknown / row end
+                        if (ext & 0x80000000u) ext = (ext & 0x7fffffffu) + (o & 0x7fffffffu) + (o & 0x80000000u);
+                    }
+                }
+                uint32_t extn = __shfl_down(ext, 1, 64);           // continuation available in the next word
+                if (lane == 63) extn = 0x80000000u;                  // unknown beyond the chunk: read the plane
                 int idx = base + (int)total + (int)(incl - c);
                 while (st) {
                     int s = __ffsll((unsigned long long)st) - 1;
@@ -571,12 +587,17 @@ __global__ __launch_bounds__(256) void k_runs(SegState S, int nrows)
                     uint64_t t = ~(v >> s);                       // zeros mark the run's extent from bit s
                     int ones = t ? __ffsll((unsigned long long)t) - 1 : 64;
                     int xe = 64 * w + s + ones - 1;
-                    if (s + ones == 64) {                           // run continues into the next words
-                        for (int k = w + 1; k < S.WW; k++) {
-                            uint64_t u = rb[k];
-                            if (u == ~0ull) { xe += 64; continue; }
-                            xe += __ffsll((unsigned long long)~u) - 1;
-                            break;
+                    if (s + ones == 64 && w + 1 < S.WW) {           // run continues into the next words
+                        if (!(extn & 0x80000000u)) xe += (int)extn;
+                        else {                                      // reaches the end of the chunk (rows wider than 4096 px) or of the row
+                            int k = w + 1;
+                            if (lane != 63) { xe += (int)(extn & 0x7fffffffu); k = w0 + 64; }
+                            for (; k < S.WW; k++) {
+                                uint64_t u = rb[k];
+                                if (u == ~0ull) { xe += 64; continue; }
+                                xe += __ffsll((unsigned long long)~u) - 1;
+                                break;
+                            }
                         }
                     }
                     S.run_x[idx] = (uint32_t)(64 * w + s) | ((uint32_t)xe << 16);

@@ -208,37 +208,6 @@ PSEG_HD void bbox_flush(const SegState &S, int E, int xs, int xe, int y)
     if (y > S.maxy[E]) PSEG_ATOMIC_MAX(&S.maxy[E], y);
 }
 
-// ---- spans of the hole-filled objects in one row ------------------------------------------------
-struct SpanIter { int rs, n, bb, f, e; };
-PSEG_HD void span_begin(const SegState &S, SpanIter &it, int f, int y)
-{
-    it.rs = seg_rowstart(S, f, y); it.n = seg_rowcount(S, f, y);
-    it.bb = it.rs + f * S.H + y; it.f = f; it.e = 1;    // element 0 is always outside
-}
-PSEG_HD int span_elem_id(const SegState &S, const SpanIter &it, int e)
-{
-    if (e & 1) return S.ext[it.rs + (e >> 1)];
-    return S.gapl[it.rs + (e >> 1)];                     // 0 < e < 2n: an inner gap
-}
-PSEG_HD bool span_next(const SegState &S, SpanIter &it, int &id, int &xs, int &xe)
-{
-    const int last = 2 * it.n;                          // element 2n is always outside
-    while (it.e < last) {
-        int cid = span_elem_id(S, it, it.e);
-        if (cid < 0) { it.e++; continue; }
-        int e = it.e;
-        xs = (e & 1) ? run_xs(S, it.rs + (e >> 1)) : run_xe(S, it.rs + (e >> 1) - 1) + 1;
-        do {
-            e = it.e;
-            xe = (e & 1) ? run_xe(S, it.rs + (e >> 1)) : run_xs(S, it.rs + (e >> 1)) - 1;
-            it.e++;
-        } while (it.e < last && span_elem_id(S, it, it.e) == cid);
-        id = cid;
-        return true;
-    }
-    return false;
-}
-
 // ---- 7. contour area from 2x2 quads of the filled object ---------------------------------------
 // A span = maximal stretch of a row that lies in the hole-filled region of one object: runs of the object (and of
 // components nested in it) joined by the gaps it fills; a span begins and ends with a run (a filled gap always has a run
@@ -280,28 +249,3 @@ PSEG_HD void area_body(const SegState &S, int r)
 
 // classification of a run as the root of an external component
 PSEG_HD bool is_ext_root(const SegState &S, int r) { return S.fg_parent[r] == r && S.ext[r] == r; }
-
-// ---- 8. one 32-pixel word of the cumulative filled mask window of a saved object ---------------
-// Window row y, columns [x0, x1] (x1 - x0 <= 31).  A pixel is set iff it lies in the hole-filled region
-// of a SAVED object (objflag & 2) iterated at or before the owner (root index >= root):
-// detection.py:206,245-246 -- the frame mask accumulates over the object loop.
-PSEG_HD uint32_t mask_word_body(const SegState &S, const int32_t *objflag, int f, int y, int x0, int x1, int root)
-{
-    int rs = seg_rowstart(S, f, y), n = seg_rowcount(S, f, y), bb = rs + f * S.H + y;
-    int lo = 0, hi = n;                                  // first run j with xe >= x0
-    while (lo < hi) { int m = (lo + hi) >> 1; if (run_xe(S, rs + m) >= x0) hi = m; else lo = m + 1; }
-    uint32_t bitsv = 0;
-    for (int e = 2 * lo; e <= 2 * n; e++) {              // gap before run lo, run lo, gap, ...
-        int j = e >> 1, xs, xe, id;
-        if (e & 1) { xs = run_xs(S, rs + j); xe = run_xe(S, rs + j); }
-        else { xs = j == 0 ? -1 : run_xe(S, rs + j - 1) + 1; xe = j == n ? S.W : run_xs(S, rs + j) - 1; }
-        if (xs > x1) break;
-        if (xe < x0) continue;
-        id = (e & 1) ? S.ext[rs + j] : ((j == 0 || j == n) ? -1 : bg_gid(S, f, bb + j));
-        if (id < 0 || id < root || !(objflag[id] & 2)) continue;
-        int a = xs > x0 ? xs : x0, b = xe < x1 ? xe : x1;
-        uint32_t m = (b - a == 31) ? 0xffffffffu : (((1u << (b - a + 1)) - 1u) << (a - x0));
-        bitsv |= m;
-    }
-    return bitsv;
-}

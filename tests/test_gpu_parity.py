@@ -203,3 +203,38 @@ def test_frame_range_parts_equal_whole_batch(gpu_seg_factory):
             if k == "shard_of_saved":
                 continue
             np.testing.assert_array_equal(got[k], ref[k], err_msg=f"world {world}: {k}")
+
+
+def test_rows_wider_than_one_wave_of_words(gpu_seg_factory):
+    """W = 4160 = 65 words: the run kernels work in chunks of 64 words; runs that cross or span the chunk boundary,
+    a full-width run, and P / 8 not a multiple of the block size (padding lanes of the dense kernels)."""
+    import torch
+    H, W, n = 33, 4160, 13
+    seg = gpu_seg_factory(H, W)
+    rng = np.random.default_rng(21)
+    cleaned = np.full((n, H, W), 255, np.uint8)
+    for f in range(n):
+        img = cleaned[f]
+        img[2:5, 4000:4160] = 40                           # ends at the right frame edge, crosses word 63 -> 64
+        img[7:9, 10:4150] = 90                             # spans all 65 words
+        img[11, :] = 30                                    # full row
+        img[14:20, 4090:4100] = 10                         # entirely in the last word
+        img[14:30, 4030:4097] = 60                         # starts in word 62, ends in word 64
+        img[22:31, 100:600] = rng.integers(0, 200, (9, 500), dtype=np.uint8)
+        sp = rng.random((H, W)) < 0.002
+        img[sp] = 0
+    items = [(cleaned[f], cleaned[f], [100.0, 50.0], f"w_{f:03d}.png") for f in range(n)]
+    dets = helpers.oracle_detect(items, None, min_area_to_segment=2, min_area_to_save=50, mask_img=False)
+    labels = torch.empty((n, H, W), dtype=torch.int32, device="cuda")
+    tab = seg.detect(torch.from_numpy(cleaned).cuda(), min_area_to_segment=2, min_area_to_save=50, labels=labels, fetch_crops=True)
+    helpers.compare_table(tab, dets, H, W, labels=labels.cpu().numpy())
+    # the fused path over the same geometry (raw stack -> background kernel with padding lanes)
+    stack = rng.integers(0, 256, (n, H, W), dtype=np.uint8)
+    its = helpers.oracle_bgcorrect(stack)
+    cl, ms, valid, tab2 = seg.process(torch.from_numpy(stack).cuda(), threshold=120)
+    cl = cl.cpu().numpy()
+    for i, it in enumerate(its):
+        np.testing.assert_allclose(ms[i], it[2], rtol=1e-9, atol=1e-9)
+        assert np.array_equal(cl[i], it[1])
+        thr = (255 - it[1]) > 120
+        assert tab2.frame_n_contours[i] == len(helpers.cv_ref.findContours(thr.astype(np.uint8), 0, 2)[0])
