@@ -66,7 +66,7 @@ struct pseg_ctx {
         keptrank, savedrank, objlabel, objflag;
     DevBuf rows, saved_row, saved_geo, crop_off, bits_off, maskbits, crops_raw, crops_masked, crops_mask;
     bool have_bits = false;       // threshold plane + masked sums already produced by the bg kernel
-    DevBuf bounds, band_off, band_obj, trash;
+    DevBuf bounds, band_off, band_obj, trash, rp_small, rp_scratch;
     int bounds_n = -1, bounds_emit = -1, bounds_chunks = -1;
     int bg_chunks = 1;            // time chunks of the streaming background kernel (PSEG_BG_CHUNKS)
     bool force_generic = false;   // PSEG_BG_GENERIC=1: use the 12x-read reference kernel (debug / cross-check)
@@ -1002,13 +1002,14 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 //  phase 2: crops (detection.py:243-247) and the sums, combined across bands with integer atomics (exact).
 // sums[s*PSEG_NSUMS + k]: 0 N, 1 sum r, 2 sum c, 3 sum r^2, 4 sum c^2, 5 sum r*c, 6 min I, 7 max I, 8 sum I,
 //   9 filled area, 10..12 perimeter code counts (weight 1, sqrt2, (1+sqrt2)/2), 13 euler, 14 convex area
+template <bool DENSE>
 __global__ __launch_bounds__(256) void k_crops_sums(SegState S, int n_saved, const int32_t *__restrict__ geo,
                                                     const long long *__restrict__ crop_off, const long long *__restrict__ band_off,
                                                     const int32_t *__restrict__ objflag, const uint8_t *__restrict__ cleaned,
                                                     const uint8_t *__restrict__ raw, uint8_t *__restrict__ c_raw,
                                                     uint8_t *__restrict__ c_masked, uint8_t *__restrict__ c_mask, long long *sums,
                                                     const long long *__restrict__ row_off, int32_t *__restrict__ rowext,
-                                                    const int32_t *__restrict__ band_obj)
+                                                    const int32_t *__restrict__ band_obj, const uint8_t *__restrict__ dense_mask)
 {
     __shared__ uint32_t mbuf[CROP_LDS_WORDS];             // mask bits of rows r0-2 .. r1+1 (zero outside the window)
     __shared__ uint32_t bd[CROP_LDS_WORDS];               // 4-neighbour border bits of rows r0-1 .. r1
@@ -1023,7 +1024,19 @@ __global__ __launch_bounds__(256) void k_crops_sums(SegState S, int n_saved, con
     for (int wi = threadIdx.x; wi < (nrows + 4) * wpr; wi += 256) mbuf[wi] = 0;
     if (threadIdx.x < 32) acc[threadIdx.x] = threadIdx.x == 15 ? 255u : 0u;    // acc[15] = running minimum
     __syncthreads();
-    {
+    if (DENSE) {
+        // pseg_regionprops: the mask is a dense uint8 image (nonzero = set) of row stride S.W instead of the run tables
+        for (int wi = threadIdx.x; wi < (nrows + 4) * wpr; wi += 256) {
+            const int yl = wi / wpr, wx = wi - yl * wpr, yy = r0 - 2 + yl;
+            uint32_t v = 0;
+            if (yy >= 0 && yy < h) {
+                const uint8_t *mrow8 = dense_mask + (size_t)(by + yy) * S.W + bx + 32 * wx;
+                const int nb = w - 32 * wx < 32 ? w - 32 * wx : 32;
+                for (int k = 0; k < nb; k++) v |= (uint32_t)(mrow8[k] != 0) << k;
+            }
+            mbuf[wi] = v;
+        }
+    } else {
         // 16 threads per row walk the row's runs; a run paints itself and the gap on its left when the object that fills
         // them (ext / gapl) is saved and was iterated at or before this one.  Two dependent global loads per row.
         const int sub = threadIdx.x & 15, x_lo = bx, x_hi = bx + w - 1;
@@ -1326,13 +1339,19 @@ __global__ __launch_bounds__(128) void k_convex(int n_saved, const int32_t *__re
     const int32_t *re = rowext + 2 * row_off[s];
     for (int i = threadIdx.x; i < 2 * h; i += 128) fl[i] = re[i];
     __syncthreads();
+    // rows without a set pixel (possible between the components of a dense mask, pseg_regionprops) give no hull points:
+    // their profile values lie beyond every real column, small enough for the 32-bit cross products
+    const int LINF = 20000, UINF = -20000;
     for (int i = threadIdx.x; i < np; i += 128) {
         const int r = i >> 1;
         int l, u;
-        if (i & 1) { l = 2 * fl[2 * r] - 1; u = 2 * fl[2 * r + 1] + 1; }
-        else {
-            const int la = r > 0 ? 2 * fl[2 * r - 2] : 0x3fffffff, lb = r < h ? 2 * fl[2 * r] : 0x3fffffff;
-            const int ua = r > 0 ? 2 * fl[2 * r - 1] : -0x3fffffff, ub = r < h ? 2 * fl[2 * r + 1] : -0x3fffffff;
+        auto lo_of = [&](int row) { return (row >= 0 && row < h && fl[2 * row + 1] >= 0) ? 2 * fl[2 * row] : LINF; };
+        auto hi_of = [&](int row) { return (row >= 0 && row < h && fl[2 * row + 1] >= 0) ? 2 * fl[2 * row + 1] : UINF; };
+        if (i & 1) {
+            const bool has = fl[2 * r + 1] >= 0;
+            l = has ? 2 * fl[2 * r] - 1 : LINF; u = has ? 2 * fl[2 * r + 1] + 1 : UINF;
+        } else {
+            const int la = lo_of(r - 1), lb = lo_of(r), ua = hi_of(r - 1), ub = hi_of(r);
             l = la < lb ? la : lb; u = ua > ub ? ua : ub;
         }
         pvl[i] = l; pvu[i] = u;
@@ -1391,7 +1410,7 @@ extern "C" int pseg_destroy(pseg_ctx *ctx)
                       &ctx->bg_parent, &ctx->bg_left, &ctx->minx, &ctx->maxx, &ctx->maxy, &ctx->area2,
                       &ctx->extrank, &ctx->keptrank, &ctx->savedrank, &ctx->objlabel, &ctx->objflag, &ctx->rows,
                       &ctx->saved_row, &ctx->saved_geo, &ctx->crop_off, &ctx->bits_off, &ctx->maskbits,
-                      &ctx->crops_raw, &ctx->crops_masked, &ctx->crops_mask, &ctx->bounds, &ctx->band_off, &ctx->band_obj, &ctx->trash};
+                      &ctx->crops_raw, &ctx->crops_masked, &ctx->crops_mask, &ctx->bounds, &ctx->band_off, &ctx->band_obj, &ctx->trash, &ctx->rp_small, &ctx->rp_scratch};
     for (DevBuf *b : bufs) if (b->p) hipFree(b->p);
     for (PinBuf *b : {&ctx->pin_head, &ctx->pin_tail, &ctx->pin_nfg}) if (b->p) hipHostFree(b->p);
     for (auto &e : ctx->ev) if (e) hipEventDestroy(e);
@@ -1520,6 +1539,51 @@ extern "C" int pseg_bgcorrect(pseg_ctx *ctx, const uint8_t *frames, int n, int n
     if (r) return r;
     HIPCHK(hipEventElapsedTime(&ctx->ms[0], ctx->ev[0], ctx->ev[1]));
     return PSEG_OK;
+}
+
+// the 32 columns of regionprop2zooprocess (detection.py:84-152, scikit-image definitions per SURVEY.md 8(a)) from the exact
+// integer sums of one window; q[9] is set to the filled area
+static void props_from_sums(int64_t *q, double w, double h, double *p)
+{
+    q[9] = q[0];                                         // filled area (see FA below)
+    const double N = (double)q[0];
+    const double cr = q[1] / N, cc = q[2] / N;
+    const double mu20 = q[3] / N - cr * cr, mu02 = q[4] / N - cc * cc, mu11 = q[5] / N - cr * cc;
+    const double a = mu02, b = -mu11, c = mu20;       // inertia tensor [[a,b],[b,c]]
+    const double tr = 0.5 * (a + c), dt = sqrt(0.25 * (a - c) * (a - c) + b * b);
+    double l1 = tr + dt, l2 = tr - dt;
+    if (l1 < 0) l1 = 0;
+    if (l2 < 0) l2 = 0;
+    const double major = 4 * sqrt(l1), minor = 4 * sqrt(l2);
+    double orient = (a - c == 0) ? (b < 0 ? -M_PI / 4 : M_PI / 4) : 0.5 * atan2(-2 * b, c - a);
+    // detection.py:84-152 in emitted order; scikit-image definitions per SURVEY.md 8(a) R9-table
+    const double FA = N;            // filled_area: a window of hole-filled objects has no 8-connected holes
+    const double perim = (double)q[10] + (double)q[11] * sqrt(2.0) + (double)q[12] * ((1.0 + sqrt(2.0)) / 2.0);
+    const double meanI = q[8] / N;
+    const double conv = q[14] >= 0 ? (double)q[14] : NAN;
+    p[0] = w; p[1] = h; p[2] = 0; p[3] = 0;
+    p[4] = (4 * M_PI * FA) / (perim * perim);          // circ.
+    p[5] = N;                                            // area_exc
+    p[6] = FA;                                           // area_rprops
+    p[7] = 1 - N / FA;                                   // %area
+    p[8] = major; p[9] = minor; p[10] = cr; p[11] = cc;
+    p[12] = conv;                                        // convex_area
+    p[13] = (double)q[6]; p[14] = (double)q[7]; p[15] = meanI;
+    p[16] = FA * meanI;                                  // intden
+    p[17] = perim;                                       // perim.
+    p[18] = major / minor;                               // elongation (inf / nan like np.divide)
+    p[19] = (double)(uint8_t)(q[7] - q[6]);              // range (uint8 arithmetic)
+    p[20] = perim / N;                                   // perimareaexc
+    p[21] = perim / major;                               // perimmajor
+    p[22] = (4 * M_PI * N) / (perim * perim);            // circex
+    p[23] = orient / M_PI * 180 + 90;                    // angle
+    p[24] = w * h;                                       // bounding_box_area
+    p[25] = l1 == 0 ? 0 : sqrt(1 - l2 / l1);             // eccentricity
+    p[26] = sqrt(4 * N / M_PI);                          // equivalent_diameter
+    p[27] = (double)q[13];                               // euler_number
+    p[28] = N / (w * h);                                 // extent
+    p[29] = cc; p[30] = cr;                              // local_centroid_col / _row
+    p[31] = N / conv;                                    // solidity
 }
 
 // rows (10 columns of stride rcap -> stride n_rows), saved_row and crop_off into the packed output arena
@@ -1670,11 +1734,11 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
         hipLaunchKernelGGL(k_band_map, dim3(nblocks((size_t)n_saved, 4)), dim3(256), 0, st, n_saved, (const long long *)ctx->band_off.p,
                            (int32_t *)ctx->band_obj.p);
         hipLaunchKernelGGL(k_init_sums, dim3(nblocks((size_t)n_saved * PSEG_NSUMS)), dim3(256), 0, st, d_sums, n_saved);
-        hipLaunchKernelGGL(k_crops_sums, dim3((unsigned)h_tot[2]), dim3(256), 0, st, S, n_saved, (const int32_t *)geo,
+        hipLaunchKernelGGL(k_crops_sums<false>, dim3((unsigned)h_tot[2]), dim3(256), 0, st, S, n_saved, (const int32_t *)geo,
                            (const long long *)ctx->crop_off.p, (const long long *)ctx->band_off.p, (const int32_t *)objflag,
                            cleaned, raw, (uint8_t *)ctx->crops_raw.p, (uint8_t *)ctx->crops_masked.p,
                            (uint8_t *)ctx->crops_mask.p, d_sums, (const long long *)ctx->bits_off.p,
-                           (int32_t *)ctx->maskbits.p, (const int32_t *)ctx->band_obj.p);
+                           (int32_t *)ctx->maskbits.p, (const int32_t *)ctx->band_obj.p, (const uint8_t *)nullptr);
         const int hmax = (int)h_tot[3];
         // two size classes: objects up to 256 rows keep 10 KB of LDS per block, the rest is sized by the tallest one
         const int hsmall = hmax < 256 ? hmax : 256;
@@ -1730,49 +1794,8 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
         h_s8[i] = (uint8_t)hrows[8 * hr + i];
     }
     for (int s = 0; s < n_saved; s++) {
-        int i = h_saved_row[s];
-        int64_t *q = h_sums + (size_t)s * PSEG_NSUMS;
-        q[9] = q[0];                                         // filled area (see FA below)
-        double *p = h_props + (size_t)s * PSEG_NPROPS;
-        const double w = hrows[6 * hr + i], h = hrows[7 * hr + i];
-        const double N = (double)q[0];
-        const double cr = q[1] / N, cc = q[2] / N;
-        const double mu20 = q[3] / N - cr * cr, mu02 = q[4] / N - cc * cc, mu11 = q[5] / N - cr * cc;
-        const double a = mu02, b = -mu11, c = mu20;       // inertia tensor [[a,b],[b,c]]
-        const double tr = 0.5 * (a + c), dt = sqrt(0.25 * (a - c) * (a - c) + b * b);
-        double l1 = tr + dt, l2 = tr - dt;
-        if (l1 < 0) l1 = 0;
-        if (l2 < 0) l2 = 0;
-        const double major = 4 * sqrt(l1), minor = 4 * sqrt(l2);
-        double orient = (a - c == 0) ? (b < 0 ? -M_PI / 4 : M_PI / 4) : 0.5 * atan2(-2 * b, c - a);
-        // detection.py:84-152 in emitted order; scikit-image definitions per SURVEY.md 8(a) R9-table
-        const double FA = N;            // filled_area: a window of hole-filled objects has no 8-connected holes
-        const double perim = (double)q[10] + (double)q[11] * sqrt(2.0) + (double)q[12] * ((1.0 + sqrt(2.0)) / 2.0);
-        const double meanI = q[8] / N;
-        const double conv = q[14] >= 0 ? (double)q[14] : NAN;
-        p[0] = w; p[1] = h; p[2] = 0; p[3] = 0;
-        p[4] = (4 * M_PI * FA) / (perim * perim);          // circ.
-        p[5] = N;                                            // area_exc
-        p[6] = FA;                                           // area_rprops
-        p[7] = 1 - N / FA;                                   // %area
-        p[8] = major; p[9] = minor; p[10] = cr; p[11] = cc;
-        p[12] = conv;                                        // convex_area
-        p[13] = (double)q[6]; p[14] = (double)q[7]; p[15] = meanI;
-        p[16] = FA * meanI;                                  // intden
-        p[17] = perim;                                       // perim.
-        p[18] = major / minor;                               // elongation (inf / nan like np.divide)
-        p[19] = (double)(uint8_t)(q[7] - q[6]);              // range (uint8 arithmetic)
-        p[20] = perim / N;                                   // perimareaexc
-        p[21] = perim / major;                               // perimmajor
-        p[22] = (4 * M_PI * N) / (perim * perim);            // circex
-        p[23] = orient / M_PI * 180 + 90;                    // angle
-        p[24] = w * h;                                       // bounding_box_area
-        p[25] = l1 == 0 ? 0 : sqrt(1 - l2 / l1);             // eccentricity
-        p[26] = sqrt(4 * N / M_PI);                          // equivalent_diameter
-        p[27] = (double)q[13];                               // euler_number
-        p[28] = N / (w * h);                                 // extent
-        p[29] = cc; p[30] = cr;                              // local_centroid_col / _row
-        p[31] = N / conv;                                    // solidity
+        const int i = h_saved_row[s];
+        props_from_sums(h_sums + (size_t)s * PSEG_NSUMS, hrows[6 * hr + i], hrows[7 * hr + i], h_props + (size_t)s * PSEG_NPROPS);
     }
     if (out) {
         memset(out, 0, sizeof(*out));
@@ -1865,6 +1888,55 @@ extern "C" int pseg_fetch_crops(pseg_ctx *ctx, uint8_t *raw, uint8_t *masked, ui
     if (masked) HIPCHK(hipMemcpyAsync(masked, ctx->crops_masked.p, nb, hipMemcpyDeviceToHost, ctx->stream));
     if (mask) HIPCHK(hipMemcpyAsync(mask, ctx->crops_mask.p, nb, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    return PSEG_OK;
+}
+
+// calculate_regionprops(mask, img) (detection.py:75-159) for one window given as dense device images: the same band
+// kernel as the fused path with the mask read from memory instead of painted from the run tables.
+extern "C" int pseg_regionprops(pseg_ctx *ctx, const uint8_t *mask, const uint8_t *img, int h, int w, int stride, double *props,
+                                int64_t *sums_out)
+{
+    if (!ctx) return PSEG_ERR_ARG;
+    if (!mask || !img || !props || h < 1 || w < 1 || w > 8192 || h > 65535 || stride < w) return fail(ctx, PSEG_ERR_ARG, "bad window");
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t lds = (size_t)h * HULL_LDS_PER_ROW + 64;
+    if (lds > 150 * 1024) return fail(ctx, PSEG_ERR_CAPACITY, "window too tall for the convex-hull kernel (limit 2700 rows)");
+    hipStream_t st = ctx->stream;
+    const int rpb = crop_rows_per_band(w), nbands = (h + rpb - 1) / rpb;
+    // small tables: geo[8] | crop_off[2] | band_off[2] | row_off[2] (long long) | band_obj[nbands] | sums[24] | rowext[2h]
+    const size_t o_geo = 0, o_ll = 64, o_bobj = o_ll + 6 * 8, o_sums = (o_bobj + (size_t)nbands * 4 + 7) & ~(size_t)7;
+    const size_t o_ext = o_sums + PSEG_NSUMS * 8, o_end = o_ext + (size_t)h * 2 * 4;
+    ENSURE(ctx->rp_small, o_end);
+    ENSURE(ctx->rp_scratch, (size_t)3 * w * h + 64);
+    std::vector<char> hb(o_sums, 0);
+    int32_t *g = (int32_t *)(hb.data() + o_geo);
+    g[0] = 0; g[1] = 0; g[2] = 0; g[3] = w; g[4] = h; g[5] = 0; g[6] = (w + 31) >> 5; g[7] = 0;
+    long long *ll = (long long *)(hb.data() + o_ll);
+    ll[0] = 0; ll[1] = (long long)w * h; ll[2] = 0; ll[3] = nbands; ll[4] = 0; ll[5] = h;
+    char *d = (char *)ctx->rp_small.p;
+    HIPCHK(hipMemcpyAsync(d, hb.data(), o_sums, hipMemcpyHostToDevice, st));
+    SegState S;
+    memset(&S, 0, sizeof(S));
+    S.F = 1; S.H = h; S.W = stride; S.WW = (stride + 63) / 64;
+    long long *d_sums = (long long *)(d + o_sums);
+    uint8_t *c0 = (uint8_t *)ctx->rp_scratch.p;
+    hipLaunchKernelGGL(k_init_sums, dim3(1), dim3(256), 0, st, d_sums, 1);
+    hipLaunchKernelGGL(k_crops_sums<true>, dim3(nbands), dim3(256), 0, st, S, 1, (const int32_t *)(d + o_geo), (const long long *)(d + o_ll),
+                       (const long long *)(d + o_ll + 16), (const int32_t *)nullptr, img, img, c0, c0 + (size_t)w * h, c0 + (size_t)2 * w * h,
+                       d_sums, (const long long *)(d + o_ll + 32), (int32_t *)(d + o_ext), (const int32_t *)(d + o_bobj), mask);
+    if (lds > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void *)k_convex, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_convex, dim3(1), dim3(128), lds, st, 1, (const int32_t *)(d + o_geo), (const long long *)(d + o_ll + 32),
+                       (const int32_t *)(d + o_ext), d_sums, 0, h);
+    HIPCHK(hipGetLastError());
+    int64_t q[PSEG_NSUMS];
+    HIPCHK(hipMemcpyAsync(q, d_sums, sizeof(q), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (q[0] == 0) {                                        // empty mask: scikit-image finds no region, the reference would raise
+        for (int k = 0; k < PSEG_NPROPS; k++) props[k] = NAN;
+        return fail(ctx, PSEG_ERR_ARG, "mask has no set pixel");
+    }
+    props_from_sums(q, (double)w, (double)h, props);
+    if (sums_out) memcpy(sums_out, q, sizeof(q));
     return PSEG_OK;
 }
 

@@ -37,6 +37,17 @@ class DetectionSettings:
     mask_radius: int
 
 
+def calculate_regionprops(mask, img, device=0):
+    """detection.py:75-159: the 32 zooprocess-style properties of one mask window (mask == nonzero) over ``img``, as the
+    dict the reference builds, computed on the GPU (``pseg_regionprops``).  mask / img: 2-D uint8 arrays."""
+    import torch
+    seg = _segmenter(2560, 2560, 1, device)
+    m = torch.from_numpy(np.ascontiguousarray(mask, dtype=np.uint8)).to(f"cuda:{device}")
+    g = torch.from_numpy(np.ascontiguousarray(img, dtype=np.uint8)).to(f"cuda:{device}")
+    vals = seg.regionprops(m, g)
+    return {k: (int(v) if k in _INT_PROPS else float(v)) for k, v in zip(PROP_KEYS, vals)}
+
+
 def save_crop_data(path, data):
     """detection.py:61-73."""
     with open(path, "w", newline="") as f:

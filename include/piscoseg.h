@@ -117,6 +117,15 @@ int pseg_process_part(pseg_ctx *ctx, const uint8_t *frames, int n_avail, int n_e
  * (any may be NULL).  Replaces the arrays handed to cv.imwrite (detection.py:251-253). */
 int pseg_fetch_crops(pseg_ctx *ctx, uint8_t *raw, uint8_t *masked, uint8_t *mask);
 
+/* calculate_regionprops(mask, img) (detection.py:75-159) for one window: the 32 columns of regionprop2zooprocess in the
+ * reference's order.  mask [dev] u8 (nonzero = region pixel), img [dev] u8, both h rows of `stride` bytes, w <= 8192,
+ * h <= 2700; props [host] double[32]; sums_out [host] int64[PSEG_NSUMS] or NULL.  The window must be the region's
+ * bounding box (as in the reference, where bx = by = 0 and width / height are the window's) and hold no background
+ * hole (8-connected) -- true for every window detect_on_img passes, whose masks are drawn FILLED (detection.py:245):
+ * filled_area is taken equal to area.  An empty mask is an error (the reference indexes regionprops(...)[0]). */
+int pseg_regionprops(pseg_ctx *ctx, const uint8_t *mask, const uint8_t *img, int h, int w, int stride,
+                     double *props, int64_t *sums_out);
+
 /* cv.circle(mask, (W/2, H/2), radius, 255, -1) on the device (detection.py:315-326). mask [dev] u8[H][W]. */
 int pseg_disk_mask(pseg_ctx *ctx, int radius, uint8_t *mask);
 

@@ -91,3 +91,35 @@ def test_correct_img_single_index():
         got = q.get()
         assert np.array_equal(got[1], want[i][1])
         np.testing.assert_allclose(got[2], want[i][2], rtol=1e-9)
+
+
+def test_calculate_regionprops_signature():
+    """detection.calculate_regionprops(mask, img) -> dict of the 32 columns, against the scikit-image-pinned oracle on
+    windows without background holes (what detect_on_img passes: masks drawn FILLED)."""
+    from scipy import ndimage as ndi
+    from imageprocessing_amd import detection
+    from oracle import regionprops_ref
+    rng = np.random.default_rng(3)
+    for case, (h, w) in enumerate([(40, 3), (25, 37), (64, 64), (90, 131), (300, 200), (17, 260), (121, 33), (5, 5)]):
+        m = np.zeros((h, w), bool)
+        yy, xx = np.mgrid[0:h, 0:w]
+        for _ in range(1 + case % 4):
+            cy, cx = rng.integers(0, h), rng.integers(0, w)
+            ry, rx = rng.integers(2, max(3, h // 2)), rng.integers(2, max(3, w // 2))
+            m |= ((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 <= 1.0
+        m[rng.integers(0, h), rng.integers(0, w)] = True                # an isolated pixel: several components
+        m = ndi.binary_fill_holes(m, structure=np.ones((3, 3)))
+        rows, cols = np.nonzero(m.any(1))[0], np.nonzero(m.any(0))[0]
+        m = m[rows[0]:rows[-1] + 1, cols[0]:cols[-1] + 1]               # the window is the region's bounding box
+        h, w = m.shape
+        mask = m.astype(np.uint8) * 255
+        img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        got = detection.calculate_regionprops(mask, img)
+        want = regionprops_ref.calculate_regionprops(mask, img)
+        assert list(got.keys()) == list(want.keys())
+        for k in want:
+            a, b = float(got[k]), float(want[k])
+            if np.isnan(b) or np.isinf(b):
+                assert (np.isnan(a) and np.isnan(b)) or (np.isinf(a) and np.isinf(b)), (case, k)
+            else:
+                np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-7, err_msg=f"case {case} {k}")
