@@ -51,7 +51,7 @@ struct pseg_ctx {
     hipEvent_t ev[8] = {};
     float ms[6] = {};
     // dense workspaces
-    DevBuf bits, partials, rowspans;
+    DevBuf bits, partials, maskpart, rowspans;
     // head arena: every small per-frame table the host needs, contiguous so that ONE copy fetches it.
     // fsums / valid_dev / maskcnt / totals / ftot are views into it (head_setup), not allocations.
     DevBuf head, fsums, valid_dev, maskcnt, totals, ftot;
@@ -65,6 +65,7 @@ struct pseg_ctx {
     DevBuf run_x, run_fy, fg_parent, ext, gapl, runlabel, bg_parent, bg_left, minx, maxx, maxy, area2, extrank,
         keptrank, savedrank, objlabel, objflag;
     DevBuf rows, saved_row, saved_geo, crop_off, bits_off, maskbits, crops_raw, crops_masked, crops_mask;
+    bool mask_counted = false;    // maskcnt already holds the number of mask == 255 pixels (fused background kernel)
     bool have_bits = false;       // threshold plane + masked sums already produced by the bg kernel
     DevBuf bounds, band_off, band_obj, trash, rp_small, rp_scratch;
     int bounds_n = -1, bounds_emit = -1, bounds_chunks = -1;
@@ -123,6 +124,7 @@ static int head_setup(pseg_ctx *ctx, int n)
     size_t o_fsums = (o_end32 + 7) & ~(size_t)7, o_maskcnt = o_fsums + (size_t)n * 32, o_totals = o_maskcnt + 8;
     size_t o_valid = o_totals + 32, o_end = o_valid + (size_t)n;
     ENSURE(ctx->head, o_end + 64);
+    ENSURE(ctx->framebase, (size_t)(n + 2) * 4);             // [n] = total runs, [n+1] = largest band (read back together)
     ENSURE_PIN(ctx->pin_head, o_end - o_ftot3 + 64);
     ENSURE_PIN(ctx->pin_nfg, 64);
     char *b = (char *)ctx->head.p;
@@ -377,7 +379,7 @@ __device__ __forceinline__ void bg_step(BgRegs &R, uint2 *ring, const BgEmit &E,
 __global__ __launch_bounds__(256, 4) void k_bg_stream(const uint8_t *__restrict__ frames, int n, size_t P, uint8_t *__restrict__ cleaned,
                                                       const uint8_t *__restrict__ mask, int thr, uint8_t *__restrict__ bits8,
                                                       uint4 *__restrict__ partials, const int *__restrict__ bounds,
-                                                      uint8_t *__restrict__ trash)
+                                                      uint8_t *__restrict__ trash, uint32_t *__restrict__ maskpart)
 {
     __shared__ uint2 lds[BG_SLOTS * 256];
     size_t strip = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -398,6 +400,10 @@ __global__ __launch_bounds__(256, 4) void k_bg_stream(const uint8_t *__restrict_
     E.kadd = thr_ok ? (uint32_t)(0x8000 - t1) * 0x00010001u : 0u;
     E.inm8 = thr_ok ? (gather4(E.inm.x & 0x80808080u) | (gather4(E.inm.y & 0x80808080u) << 4)) : 0u;
     E.nwaves = gridDim.x * 4; E.wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (mask && blockIdx.y == 0) {                          // pixels with mask == 255, per wave (summed by k_reduce_partials)
+        const uint32_t mc = wave_sum63((uint32_t)__popc(gather4(E.inm.x & 0x80808080u) | (gather4(E.inm.y & 0x80808080u) << 4)));
+        if ((threadIdx.x & 63) == 63) maskpart[E.wave] = mc;
+    }
     const uint8_t *src = frames;
     uint2 *ring = lds + threadIdx.x;
 #pragma unroll
@@ -450,10 +456,25 @@ __global__ __launch_bounds__(256) void k_threshold(const uint8_t *__restrict__ c
 // decided exactly in integers: P*sum(x^2) - sum(x)^2 > 4*P^2   (bg_correction.py:71)
 __global__ __launch_bounds__(1024) void k_reduce_partials(const uint32_t *__restrict__ partials, int nblk, unsigned long long P,
                                                           unsigned long long *__restrict__ fsums, uint8_t *__restrict__ valid,
-                                                          int setvalid, int first, int count)
+                                                          int setvalid, int first, int count,
+                                                          unsigned long long *__restrict__ cnt_totals, uint32_t *__restrict__ bandmax,
+                                                          const uint32_t *__restrict__ maskpart, int nmaskpart)
 {
     __shared__ unsigned long long red[16][4];
     int f = blockIdx.x;
+    // block 0 also clears the counters of the detection that follows (mask count | 4 totals, largest band) and, when the
+    // background kernel left per-wave counts of mask pixels, sums them
+    if (f == 0 && cnt_totals) {
+        if (threadIdx.x >= 1 && threadIdx.x < 5) cnt_totals[threadIdx.x] = 0;
+        if (threadIdx.x == 5) *bandmax = 0;
+        unsigned long long m = 0;
+        for (int b = threadIdx.x; b < nmaskpart; b += 1024) m += maskpart[b];
+        for (int o = 32; o > 0; o >>= 1) m += __shfl_down(m, o, 64);
+        __shared__ unsigned long long mred[16];
+        if ((threadIdx.x & 63) == 0) mred[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) { unsigned long long t = 0; for (int w = 0; w < 16; w++) t += mred[w]; cnt_totals[0] = t; }
+    }
     unsigned long long a[4] = {0, 0, 0, 0};
     const uint4 *p4 = (const uint4 *)partials + (size_t)f * nblk;
     for (int b = threadIdx.x; b < nblk; b += 1024) {
@@ -787,6 +808,7 @@ __global__ __launch_bounds__(256) void k_scan_rows(SegState S, uint32_t *ftot, u
 // exclusive scan over the frames by one block: out[0..F] (strided input / output)
 __global__ __launch_bounds__(256) void k_scan_small(const uint32_t *in, uint32_t *out, int F, int stride_in, int stride_out)
 {
+    in += blockIdx.x; out += (size_t)blockIdx.x * (F + 1);  // grid.x > 1: columns in, in+1, .. -> tables out, out + (F+1), ..
     __shared__ uint32_t sh[256];
     __shared__ uint32_t carry;
     if (threadIdx.x == 0) carry = 0;
@@ -981,10 +1003,12 @@ __global__ __launch_bounds__(1024) void k_scan_sizes(const unsigned long long *s
 }
 
 // band -> saved object (one wave per object), so that a band's block starts with one load instead of a binary search
-__global__ __launch_bounds__(256) void k_band_map(int n_saved, const long long *__restrict__ band_off, int32_t *__restrict__ band_obj)
+__global__ __launch_bounds__(256) void k_band_map(int n_saved, const long long *__restrict__ band_off, int32_t *__restrict__ band_obj,
+                                                  long long *__restrict__ sums)
 {
     const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (s >= n_saved) return;
+    if ((threadIdx.x & 63) < PSEG_NSUMS) sums[(size_t)s * PSEG_NSUMS + (threadIdx.x & 63)] = (threadIdx.x & 63) == 6 ? 255 : 0;   // min intensity starts at 255
     for (long long b = band_off[s] + (threadIdx.x & 63); b < band_off[s + 1]; b += 64) band_obj[b] = s;
 }
 
@@ -1405,7 +1429,7 @@ extern "C" int pseg_destroy(pseg_ctx *ctx)
     if (!ctx) return PSEG_ERR_ARG;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
-    DevBuf *bufs[] = {&ctx->bits, &ctx->partials, &ctx->head, &ctx->outpack, &ctx->rowspans, &ctx->rowcnt,
+    DevBuf *bufs[] = {&ctx->bits, &ctx->partials, &ctx->maskpart, &ctx->head, &ctx->outpack, &ctx->rowspans, &ctx->rowcnt,
                       &ctx->rowoff, &ctx->framebase, &ctx->run_x, &ctx->run_fy, &ctx->fg_parent, &ctx->ext, &ctx->gapl, &ctx->runlabel,
                       &ctx->bg_parent, &ctx->bg_left, &ctx->minx, &ctx->maxx, &ctx->maxy, &ctx->area2,
                       &ctx->extrank, &ctx->keptrank, &ctx->savedrank, &ctx->objlabel, &ctx->objflag, &ctx->rows,
@@ -1460,6 +1484,7 @@ static int run_bg(pseg_ctx *ctx, const uint8_t *frames, int n_avail, int n_emit,
     unsigned npart = stream ? nblk * 4 : nblk;               // partial sums per frame: per wave / per block
     ENSURE(ctx->bits, (size_t)n * P / 8);
     ENSURE(ctx->partials, (size_t)n * npart * 4 * sizeof(uint32_t));
+    ENSURE(ctx->maskpart, (size_t)npart * 4 + 16);
     { int r_ = head_setup(ctx, n); if (r_) return r_; }
     int chunks = 1;
     if (stream) {
@@ -1481,14 +1506,18 @@ static int run_bg(pseg_ctx *ctx, const uint8_t *frames, int n_avail, int n_emit,
     HIPCHK(hipEventRecord(ctx->ev[0], ctx->stream));
     if (stream)
         hipLaunchKernelGGL(k_bg_stream, dim3(nblk, chunks), dim3(256), 0, ctx->stream, frames, n_kernel, P, cleaned, mask, thr,
-                           (uint8_t *)ctx->bits.p, (uint4 *)ctx->partials.p, (const int *)ctx->bounds.p, (uint8_t *)ctx->trash.p);
+                           (uint8_t *)ctx->bits.p, (uint4 *)ctx->partials.p, (const int *)ctx->bounds.p, (uint8_t *)ctx->trash.p,
+                           (uint32_t *)ctx->maskpart.p);
     else
         hipLaunchKernelGGL(k_bg_generic, dim3(nblk, n), dim3(256), 0, ctx->stream, frames, n_kernel, NW, P, cleaned, mask, thr,
                            (uint8_t *)ctx->bits.p, (uint32_t *)ctx->partials.p);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
     hipLaunchKernelGGL(k_reduce_partials, dim3(n), dim3(1024), 0, ctx->stream, (const uint32_t *)ctx->partials.p, (int)npart,
-                       (unsigned long long)P, (unsigned long long *)ctx->fsums.p, (uint8_t *)ctx->valid_dev.p, 1, 0, 4);
+                       (unsigned long long)P, (unsigned long long *)ctx->fsums.p, (uint8_t *)ctx->valid_dev.p, 1, 0, 4,
+                       (unsigned long long *)ctx->maskcnt.p, (uint32_t *)ctx->framebase.p + n + 1,
+                       (const uint32_t *)ctx->maskpart.p, (stream && mask) ? (int)npart : 0);
+    ctx->mask_counted = stream && mask;
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1615,20 +1644,16 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
     S.valid = (const uint8_t *)ctx->valid_dev.p;
     ENSURE(ctx->rowcnt, (size_t)n * H * 4);
     ENSURE(ctx->rowoff, (size_t)n * (H + 1) * 4);
-    ENSURE(ctx->framebase, (size_t)(n + 2) * 4);             // [n] = total runs, [n+1] = largest band (read back together)
     { int r_ = head_setup(ctx, n); if (r_) return r_; }
     S.rowcnt = (uint32_t *)ctx->rowcnt.p; S.rowoff = (uint32_t *)ctx->rowoff.p; S.framebase = (uint32_t *)ctx->framebase.p;
     uint32_t *ftot = (uint32_t *)ctx->ftot.p;            // [n] run totals | [3n] rank totals | [n+1] rowbase | [n+1] savedbase
     uint32_t *ftot3 = ftot + n, *rowbase = ftot3 + 3 * (size_t)n, *savedbase = rowbase + (n + 1);
 
     HIPCHK(hipEventRecord(ctx->ev[2], st));
-    // maskcnt (8 B) and totals (32 B) are adjacent in the head arena: one clear; no mask = every pixel counts
-    HIPCHK(hipMemsetAsync(ctx->maskcnt.p, 0, 40, st));
-    if (mask) {
+    // (the counters were cleared by k_reduce_partials; the mask pixels were counted by the background kernel when it ran fused)
+    if (mask && !ctx->mask_counted)
         hipLaunchKernelGGL(k_mask_count, dim3(1024), dim3(256), 0, st, mask, P, (unsigned long long *)ctx->maskcnt.p);
-    }
     hipLaunchKernelGGL(k_runs<false>, dim3(nblocks((size_t)n * H, 4 * RUNS_RPW)), dim3(256), 0, st, S, n * H);
-    HIPCHK(hipMemsetAsync(S.framebase + n + 1, 0, 4, st));
     hipLaunchKernelGGL(k_scan_rows, dim3(n), dim3(256), 0, st, S, ftot, S.framebase + n + 1);
     hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(256), 0, st, (const uint32_t *)ftot, S.framebase, n, 1, 1);
     HIPCHK(hipGetLastError());
@@ -1669,8 +1694,7 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
         hipLaunchKernelGGL(k_area, dim3(nblocks(nfg)), dim3(256), 0, st, S, nfg);
     }
     hipLaunchKernelGGL(k_rank, dim3(n), dim3(1024), 0, st, S, min_seg, min_save, ftot3);
-    hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(256), 0, st, (const uint32_t *)(ftot3 + 1), rowbase, n, 3, 1);
-    hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(256), 0, st, (const uint32_t *)(ftot3 + 2), savedbase, n, 3, 1);
+    hipLaunchKernelGGL(k_scan_small, dim3(2), dim3(256), 0, st, (const uint32_t *)(ftot3 + 1), rowbase, n, 3, 1);   // rowbase | savedbase
     HIPCHK(hipGetLastError());
     // rows: one per kept object; n_rows <= external roots <= nfg bounds the buffers without a host round trip
     const size_t rcap = cap, scap = cap;
@@ -1732,8 +1756,7 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
         ENSURE(ctx->maskbits, (size_t)h_tot[1] * 2 * 4);     // first / last column of every window row (convex hull input)
         ENSURE(ctx->band_obj, (size_t)h_tot[2] * 4);
         hipLaunchKernelGGL(k_band_map, dim3(nblocks((size_t)n_saved, 4)), dim3(256), 0, st, n_saved, (const long long *)ctx->band_off.p,
-                           (int32_t *)ctx->band_obj.p);
-        hipLaunchKernelGGL(k_init_sums, dim3(nblocks((size_t)n_saved * PSEG_NSUMS)), dim3(256), 0, st, d_sums, n_saved);
+                           (int32_t *)ctx->band_obj.p, d_sums);
         hipLaunchKernelGGL(k_crops_sums<false>, dim3((unsigned)h_tot[2]), dim3(256), 0, st, S, n_saved, (const int32_t *)geo,
                            (const long long *)ctx->crop_off.p, (const long long *)ctx->band_off.p, (const int32_t *)objflag,
                            cleaned, raw, (uint8_t *)ctx->crops_raw.p, (uint8_t *)ctx->crops_masked.p,
@@ -1834,7 +1857,9 @@ extern "C" int pseg_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t 
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
     hipLaunchKernelGGL(k_reduce_partials, dim3(n), dim3(1024), 0, ctx->stream, (const uint32_t *)ctx->partials.p, (int)nblk,
-                       (unsigned long long)P, (unsigned long long *)ctx->fsums.p, (uint8_t *)ctx->valid_dev.p, 0, 2, 2);
+                       (unsigned long long)P, (unsigned long long *)ctx->fsums.p, (uint8_t *)ctx->valid_dev.p, 0, 2, 2,
+                       (unsigned long long *)ctx->maskcnt.p, (uint32_t *)ctx->framebase.p + n + 1, (const uint32_t *)nullptr, 0);
+    ctx->mask_counted = false;
     HIPCHK(hipGetLastError());
     r = run_detect(ctx, cleaned, raw, mask, n, min_area_to_segment, min_area_to_save, labels, out);
     if (r) return r;
