@@ -1,16 +1,16 @@
 #!/usr/bin/env python3
 """Turn the counter_collection.csv files of two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) into
 profiles/traffic.json: HBM bytes per launch of each kernel group, corrected as MI355X_MICROARCH.md (HBM) says:
-FETCH_SIZE is in KiB-like units of 1 KB per count on this build?  No: the CSV value is in kilobytes; gfx950 tallies
-128-B read requests at 64 B, so reads are doubled; WRITE_SIZE is taken as is.
+the CSV values are in kilobytes; gfx950 tallies 128-B read requests at 64 B, so reads are doubled; WRITE_SIZE is
+taken as is.  Groups are the ones bench.py times with HIP events (k_reduce_partials lies outside them).
 usage: pmc_to_traffic.py <fetch.csv> <write.csv> <out.json>"""
 import csv
 import json
 import sys
 from collections import defaultdict
 
-GROUP = {"k_bg_stream": "bg_correct", "k_reduce_partials": "bg_correct", "k_label_fill": "label_map",
-         "k_crops_sums": "crops_props", "k_convex": "crops_props", "k_init_sums": "crops_props"}
+GROUP = {"k_bg_stream": "bg_correct", "k_label_fill": "label_map", "k_run_labels": "label_map",
+         "k_crops_sums<false>": "crops_props", "k_convex": "crops_props", "k_band_map": "crops_props", "k_pack_out": "crops_props"}
 
 
 def per_kernel(path, counter):
@@ -35,7 +35,7 @@ def main():
         wr = write.get(k, 0.0) * 1024
         kernels[k] = {"read_bytes": rd, "write_bytes": wr, "launches_sampled": nf.get(k, 0)}
         g = GROUP.get(k, "sparse_labelling")
-        if k.startswith("k_synth") or k.startswith("k_fill_spans") or k.startswith("__amd"):
+        if k.startswith("k_synth") or k.startswith("k_fill_spans") or k.startswith("__amd") or k.startswith("k_reduce_partials"):
             continue
         groups[g] += rd + wr
     out = dict(groups)
