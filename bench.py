@@ -26,6 +26,7 @@ sys.path.insert(0, ROOT)
 H = W = 2560
 P = H * W
 BATCH = 200
+GATHER_EVERY = 4                           # batches per table gather (N > 1)
 HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: 8.0 TB/s spec peak
 PATH_BYTES_PER_FRAME = 6 * P               # raw read + cleaned write + int32 label write
 # algorithmic HBM bytes per frame of each kernel group (DESIGN.md "Kernels and rooflines")
@@ -47,6 +48,8 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=200, help="frames of the CPU-baseline sample (0 = skip); 200 = one reference batch")
     ap.add_argument("--cpu-procs", default="3,8", help="background-correction,detection processes of the CPU baseline "
                     "(reference topology: bg_correction.py:120 / segmenter.py:252); '1,1' = single core, in-process")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo + --single-device rehearses the N > 1 path on one GPU")
+    ap.add_argument("--single-device", action="store_true", help="every rank uses cuda:0 (rehearsal only; never a measurement)")
     ap.add_argument("--streams", type=int, default=2, help="contexts (own HIP stream + host thread each) that alternate batches")
     args = ap.parse_args()
 
@@ -58,11 +61,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.single_device:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group("gloo")
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
+    cdev = dev if args.backend == "nccl" else "cpu"        # where the collectives' tensors live
 
     import queue
     import threading
@@ -80,15 +89,17 @@ def main():
     cleaned = [torch.empty((BATCH, H, W), dtype=torch.uint8, device=dev) for _ in range(ns)]
     labels = [None if args.no_labels else torch.empty((BATCH, H, W), dtype=torch.int32, device=dev) for _ in range(ns)]
 
+    gatherer = sharding.TableGatherer(device=cdev) if world > 1 else None
+    wire = np.empty(256 << 20, np.uint8) if world > 1 else None     # reused by pack_table
     group_ms = {k: 0.0 for k in GROUP_NAMES}
-    stats = dict(rows=0, saved=0, crop_bytes=0, contours=0)
+    stats = dict(rows=0, saved=0, crop_bytes=0, contours=0, gather_s=0.0)
     lock = threading.Lock()
 
     def step(i, k, timed, out_q=None):
         """one batch through the fused hot path on context k"""
         _, _, _, tab = segs[k].process(stacks[i % nb], mask=mask, cleaned=cleaned[k], labels=labels[k])
         if out_q is not None:
-            out_q.put((i, sharding.pack_table(tab, frame_base=(rank * nb + i % nb) * BATCH)))
+            out_q.put((i, tab))                              # packed and gathered by the main thread
         if timed:
             with lock:
                 stats["rows"] += tab.n_rows
@@ -105,12 +116,20 @@ def main():
         for t in ths:
             t.start()
         if world > 1:
-            pending = {}
+            # tables of GATHER_EVERY consecutive batches travel in one message: fewer, larger collectives
+            pending, fill = {}, 0
             for want in range(first, first + count):
                 while want not in pending:
-                    i, blob = out_q.get()
-                    pending[i] = blob
-                sharding.gather_tables(pending.pop(want), device=dev)
+                    i, tab = out_q.get()
+                    pending[i] = tab
+                g0 = time.perf_counter()
+                blob = sharding.pack_table(pending.pop(want), frame_base=(rank * nb + want % nb) * BATCH, out=wire[fill:])
+                fill += blob.size
+                if (want - first + 1) % GATHER_EVERY == 0 or want == first + count - 1:
+                    gatherer.gather(wire[:fill])
+                    fill = 0
+                if timed:
+                    stats["gather_s"] += time.perf_counter() - g0
         for t in ths:
             t.join()
 
@@ -125,7 +144,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     # kernel-group durations for the roofline: HIP events on the library's stream, one context alone on the GPU
@@ -169,7 +188,7 @@ def main():
                      "avg_launch_ms": round(dom_ms, 4), "bytes_per_launch": int(launch_bytes)},
         "path": {"bytes_per_frame": PATH_BYTES_PER_FRAME if not args.no_labels else 2 * P,
                  "frac_of_hbm_peak_per_gpu": round(fps / world * (PATH_BYTES_PER_FRAME if not args.no_labels else 2 * P) / (HBM_PEAK_GBS * 1e9), 4),
-                 "contexts": ns,
+                 "contexts": ns, "table_gather_ms_per_step_rank0": round(stats["gather_s"] / args.steps * 1e3, 3) if world > 1 else None,
                  "group_ms_per_step_single_context": {GROUP_NAMES[k]: round(group_ms[k] / nprobe, 3) for k in GROUP_NAMES}},
     }
 

@@ -6,8 +6,6 @@ frame's background window never leaves its batch (bg_correction.py:72), so batch
 independence.  ``batches_of`` restates the reference's partition; ``assign_batches`` deals them to
 ranks; ``gather_tables`` is the only collective (RCCL when the tensors live on the GPU, gloo on CPU).
 """
-import io
-
 import numpy as np
 
 
@@ -71,23 +69,76 @@ def plan_ranges(n_files, world_size, batch_size=200, window=12):
     return out
 
 
-TABLE_FIELDS = ["frame_row_offset", "frame_n_contours", "frame_valid", "frame_mean", "frame_std", "frame", "c", "label",
-                "area", "x", "y", "w", "h", "saved", "saved_props", "saved_row", "crop_offset", "sums"]
+# (name, dtype, shape as a function of n_frames F, rows R, saved S) in wire order
+_WIRE = [
+    ("frame_row_offset", np.int32, lambda F, R, S: (F + 1,)), ("frame_n_contours", np.int32, lambda F, R, S: (F,)),
+    ("frame_valid", np.uint8, lambda F, R, S: (F,)), ("frame_mean", np.float64, lambda F, R, S: (F,)),
+    ("frame_std", np.float64, lambda F, R, S: (F,)),
+    ("frame", np.int32, lambda F, R, S: (R,)), ("c", np.int32, lambda F, R, S: (R,)), ("label", np.int32, lambda F, R, S: (R,)),
+    ("area", np.float64, lambda F, R, S: (R,)), ("x", np.int32, lambda F, R, S: (R,)), ("y", np.int32, lambda F, R, S: (R,)),
+    ("w", np.int32, lambda F, R, S: (R,)), ("h", np.int32, lambda F, R, S: (R,)), ("saved", np.uint8, lambda F, R, S: (R,)),
+    ("saved_props", np.float64, lambda F, R, S: (S, 32)), ("saved_row", np.int32, lambda F, R, S: (S,)),
+    ("crop_offset", np.int64, lambda F, R, S: (S + 1,)),
+]                                                  # (the integer sums behind the properties stay on the producing rank)
+TABLE_FIELDS = [w[0] for w in _WIRE]
+_MAGIC = 0x50534547544142                          # "PSEGTAB"
 
 
-def pack_table(tab, frame_base=0):
-    """Object table -> one uint8 blob (npz container); frame indices are made global."""
-    buf = io.BytesIO()
-    d = {k: getattr(tab, k) for k in TABLE_FIELDS}
-    d["frame"] = d["frame"] + np.int32(frame_base)
-    d["meta"] = np.asarray([tab.n_frames, frame_base, tab.crop_bytes], np.int64)
-    np.savez(buf, **d)
-    return np.frombuffer(buf.getvalue(), np.uint8).copy()
+def pack_table(tab, frame_base=0, out=None):
+    """Object table -> one uint8 blob: a 6-word int64 header, then the arrays back to back in _WIRE order (plain
+    memcpy -- this runs once per batch next to the kernels).  Frame indices are made global.  ``out``: a uint8 buffer
+    to reuse (a view of it is returned when it is large enough; fresh pages cost more than the copy)."""
+    F, R, S = int(tab.n_frames), len(tab.frame), len(tab.saved_row)
+    head = np.asarray([_MAGIC, F, frame_base, tab.crop_bytes, R, S], np.int64)
+    sizes = [int(np.prod(shape(F, R, S))) * np.dtype(dt).itemsize for _, dt, shape in _WIRE]
+    total = 48 + sum(sizes)
+    out = out[:total] if out is not None and out.size >= total else np.empty(total, np.uint8)
+    out[:48] = head.view(np.uint8)
+    o = 48
+    for (name, dt, shape), nb in zip(_WIRE, sizes):
+        a = getattr(tab, name)
+        assert a.dtype == dt and a.shape == shape(F, R, S), (name, a.dtype, a.shape)
+        dst = out[o:o + nb].view(dt).reshape(a.shape)
+        if name == "frame":
+            np.add(a, np.int32(frame_base), out=dst)
+        else:
+            dst[...] = a
+        o += nb
+    return out
+
+
+def packed_size(blob):
+    """bytes of the packed table that starts at blob[0] (several tables may be sent back to back in one message)"""
+    head = np.ascontiguousarray(blob[:48]).view(np.int64)
+    assert head[0] == _MAGIC, "not a packed object table"
+    F, R, S = int(head[1]), int(head[4]), int(head[5])
+    return 48 + sum(int(np.prod(shape(F, R, S))) * np.dtype(dt).itemsize for _, dt, shape in _WIRE)
+
+
+def split_tables(buf):
+    """the packed tables lying back to back in buf"""
+    out, o = [], 0
+    while o < buf.size:
+        n = packed_size(buf[o:])
+        out.append(buf[o:o + n])
+        o += n
+    return out
 
 
 def unpack_table(blob):
-    d = np.load(io.BytesIO(blob.tobytes()), allow_pickle=False)
-    return {k: d[k] for k in d.files}
+    blob = np.ascontiguousarray(blob, dtype=np.uint8)
+    head = blob[:48].view(np.int64)
+    assert head[0] == _MAGIC, "not a packed object table"
+    F, R, S = int(head[1]), int(head[4]), int(head[5])
+    out = {"meta": np.asarray([F, head[2], head[3]], np.int64)}
+    o = 48
+    for name, dt, shape in _WIRE:
+        shp = shape(F, R, S)
+        nb = int(np.prod(shp)) * np.dtype(dt).itemsize
+        out[name] = blob[o:o + nb].view(dt).reshape(shp).copy()
+        o += nb
+    assert o == blob.size
+    return out
 
 
 def merge_tables(parts):
@@ -96,7 +147,7 @@ def merge_tables(parts):
     parts = sorted(parts, key=lambda p: int(p["meta"][1]))
     out = {}
     for k in ("frame_n_contours", "frame_valid", "frame_mean", "frame_std", "frame", "c", "label", "area", "x", "y", "w",
-              "h", "saved", "saved_props", "sums"):
+              "h", "saved", "saved_props"):
         out[k] = np.concatenate([p[k] for p in parts])
     rows = np.cumsum([0] + [len(p["frame"]) for p in parts])
     crops = np.cumsum([0] + [int(p["meta"][2]) for p in parts])
@@ -107,23 +158,53 @@ def merge_tables(parts):
     return out
 
 
+class TableGatherer:
+    """Variable-length gather of the packed tables to rank ``dst``: an all-gather of the byte counts, then a gather of
+    the padded blobs -- the only collective of the path.  With the nccl backend (RCCL over xGMI) the blobs are staged on
+    ``device``; the buffers (device send / receive, page-locked host mirrors) are kept between calls and grow together on
+    all ranks (every rank sees the same byte counts).  ``gather`` returns the list of blobs on dst (views of a host
+    buffer that the next call overwrites), None elsewhere."""
+
+    def __init__(self, device=None, dst=0):
+        import torch.distributed as dist
+        self.dev = device if device is not None else "cpu"
+        self.dst, self.world, self.rank = dst, dist.get_world_size(), dist.get_rank()
+        self.cap = 0
+        self.on_gpu = str(self.dev) != "cpu"
+
+    def _grow(self, cap):
+        import torch
+        cap = (cap * 5 // 4 + 4095) & ~4095
+        self.send = torch.zeros(cap, dtype=torch.uint8, device=self.dev)
+        self.hsend = torch.zeros(cap, dtype=torch.uint8, pin_memory=self.on_gpu)
+        if self.rank == self.dst:
+            self.recv = torch.zeros((self.world, cap), dtype=torch.uint8, device=self.dev)
+            self.hrecv = torch.zeros((self.world, cap), dtype=torch.uint8, pin_memory=self.on_gpu) if self.on_gpu else self.recv
+        self.cap = cap
+
+    def gather(self, blob):
+        import torch
+        import torch.distributed as dist
+        n = torch.tensor([blob.size], dtype=torch.int64, device=self.dev)
+        sizes = torch.zeros(self.world, dtype=torch.int64, device=self.dev)
+        dist.all_gather(list(sizes.split(1)), n)
+        sizes = sizes.cpu().tolist()
+        need = max(sizes)
+        if need > self.cap:
+            self._grow(need)
+        self.hsend[:blob.size].numpy()[...] = blob
+        self.send[:need].copy_(self.hsend[:need], non_blocking=True)
+        recv = [self.recv[r, :need] for r in range(self.world)] if self.rank == self.dst else None
+        dist.gather(self.send[:need], recv, dst=self.dst)
+        if self.rank != self.dst:
+            return None
+        if self.on_gpu:
+            self.hrecv[:, :need].copy_(self.recv[:, :need], non_blocking=True)
+            torch.cuda.current_stream(self.recv.device).synchronize()
+        return [self.hrecv[r, :s].numpy() for r, s in enumerate(sizes)]
+
+
 def gather_tables(blob, device=None, dst=0):
-    """Variable-length gather of the packed tables to rank ``dst``: an all-gather of the byte counts,
-    then a gather of the padded blobs.  Returns the list of blobs on dst, None elsewhere.
-    With the nccl backend (RCCL over xGMI) the tensors are staged on ``device``."""
-    import torch
-    import torch.distributed as dist
-    world, rank = dist.get_world_size(), dist.get_rank()
-    dev = device if device is not None else "cpu"
-    n = torch.tensor([blob.size], dtype=torch.int64, device=dev)
-    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(sizes, n)
-    sizes = [int(s.item()) for s in sizes]
-    cap = max(sizes)
-    send = torch.zeros(cap, dtype=torch.uint8, device=dev)
-    send[:blob.size] = torch.from_numpy(blob).to(dev)
-    recv = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == dst else None
-    dist.gather(send, recv, dst=dst)
-    if rank != dst:
-        return None
-    return [r[:s].cpu().numpy() for r, s in zip(recv, sizes)]
+    """One-off form of TableGatherer.gather (the blobs are copied out of the gatherer's buffer)."""
+    got = TableGatherer(device, dst).gather(blob)
+    return None if got is None else [g.copy() for g in got]

@@ -70,6 +70,11 @@ def test_pack_merge_is_independent_of_sharding():
     for s, r in enumerate(merged["saved_row"]):
         assert merged["saved"][r] == 1
     assert merged["crop_offset"][-1] == sum(t.crop_bytes for t in shards)
+    # several tables back to back in one message (bench.py gathers a few batches at a time)
+    both = np.concatenate(blobs[:2])
+    parts = sharding.split_tables(both)
+    assert [p.size for p in parts] == [blobs[0].size, blobs[1].size]
+    assert np.array_equal(sharding.unpack_table(parts[1])["area"], shards[1].area)
 
 
 def _worker(rank, world, port, q):
