@@ -63,6 +63,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.single_device:
         local_rank = 0
+    # RCCL (and gloo) print banners to stdout when a communicator comes up; the contract is ONE JSON line on stdout, so
+    # file descriptor 1 points at stderr until that line is printed
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
@@ -215,8 +220,13 @@ def main():
         out["cpu_baseline"] = {"value": round(nf / ct, 3), "unit": "frames/s", "cores": cores, "kind": "port",
                                "sample": f"first {nf} frames of batch 0 as one batch (window 12), NumPy + C oracle, {how}, "
                                          f"no PNG/CSV writes, host has {os.cpu_count()} logical CPUs"}
+    if world > 1:
+        dist.barrier()
+    sys.stdout.flush()
+    os.dup2(real_stdout, 1)
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    os.dup2(2, 1)
     for sg in segs:
         sg.close()
     if world > 1:
