@@ -123,3 +123,40 @@ def test_calculate_regionprops_signature():
                 assert (np.isnan(a) and np.isnan(b)) or (np.isinf(a) and np.isinf(b)), (case, k)
             else:
                 np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-7, err_msg=f"case {case} {k}")
+
+
+def test_abi_error_paths_return_codes_and_text():
+    """Every entry point returns a negative code with a message instead of aborting (the reference's convention is
+    'print and carry on'); nothing here launches a kernel with bad shapes."""
+    import ctypes as C
+    import torch
+    from imageprocessing_amd import _lib
+    from imageprocessing_amd.engine import Segmenter, PsegError
+    L = _lib.load()
+    h = C.c_void_p()
+    assert L.pseg_create(0, 100, 100, 10, C.byref(h)) == -1            # W not a multiple of 64
+    assert L.pseg_create(0, 64, 16384, 10, C.byref(h)) == -1           # W > 8192
+    assert L.pseg_create(99, 64, 64, 10, C.byref(h)) == -4             # no such device
+    seg = Segmenter(64, 128, max_frames=16, device=0)
+    frames = torch.zeros((20, 64, 128), dtype=torch.uint8, device="cuda")
+    with pytest.raises(PsegError, match="out of range"):
+        seg.bgcorrect(frames)                                            # n > max_frames
+    with pytest.raises(PsegError, match="n_bg_imgs"):
+        seg.bgcorrect(frames[:4])                                        # fewer frames than n_bg_imgs
+    with pytest.raises(PsegError, match="halo"):
+        seg.process(frames[:16], n_emit=10)                              # part without its 11-frame halo
+    with pytest.raises(PsegError):
+        seg.bgcorrect(torch.zeros((4, 64, 64), dtype=torch.uint8, device="cuda"))   # wrong frame size
+    with pytest.raises(PsegError):
+        seg.bgcorrect(torch.zeros((12, 64, 128), dtype=torch.uint8))                  # host tensor
+    t = _lib.Table()
+    assert L.pseg_detect(seg.h, None, None, None, None, 4, 10, 10.0, 400.0, None, C.byref(t)) == -1
+    assert b"null" in L.pseg_last_error(seg.h)
+    props = np.zeros(32)
+    m = torch.zeros((8, 8), dtype=torch.uint8, device="cuda")
+    assert L.pseg_regionprops(seg.h, m.data_ptr(), m.data_ptr(), 8, 8, 8, props.ctypes.data, None) == -1    # empty mask
+    assert np.isnan(props).all()
+    # the context still works after the errors
+    cleaned, ms, valid = seg.bgcorrect(torch.full((12, 64, 128), 7, dtype=torch.uint8, device="cuda"))
+    assert valid.sum() == 0 and np.allclose(ms[:, 0], 7.0)
+    seg.close()
