@@ -948,7 +948,7 @@ __global__ __launch_bounds__(256) void k_label_fill(SegState S, const int32_t *_
 
 // geometry of saved object s: geo[s*8] = f, x, y, w, h, root, words-per-row, row ; sz[s*3] = crop bytes,
 // mask words, row bands (a band = a run of rows of about CROP_BAND pixels: the unit of work of k_crops_sums)
-#define CROP_BAND 8192
+#define CROP_BAND 16384
 #define CROP_LDS_WORDS 1536          // mask words of a band + 2 halo rows on each side (frames up to 8192 px wide)
 __host__ __device__ inline int crop_rows_per_band(int w)
 {
