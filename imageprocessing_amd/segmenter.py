@@ -63,11 +63,12 @@ def save_detection_settings_to_csv(settings, file_path, src_path):
             writer.writerow([field_name, getattr(settings, field_name)])
 
 
-def run_segmenter(src_path: str, save_path: str, deconvolution: bool):
-    """segmenter.py:108-265.  ``deconvolution=True`` (LUCYD between the two stages) is outside the hot path
-    and not provided here."""
-    if deconvolution:
-        raise NotImplementedError("LUCYD deconvolution is outside this library's scope (SURVEY.md 8(f) N2)")
+def run_segmenter(src_path: str, save_path: str, deconvolution: bool, model=None):
+    """segmenter.py:108-265.  With ``deconvolution=True`` the network between the two stages (LUCYD in the reference, a
+    module-level global of deconvolution.py) is passed as ``model``: any torch callable float32 [b,1,H,W] -> same shape
+    (or a tuple starting with it); the network itself is outside this library."""
+    if deconvolution and model is None:
+        raise ValueError("deconvolution=True needs model= (the reference's LUCYD module and weights live in its repository)")
     os.makedirs(save_path, exist_ok=True)
     paths = {k: os.path.join(save_path, k) for k in ("Crops", "Deconv_crops", "Masks", "Data", "Images")}
     for p in paths.values():
@@ -101,6 +102,12 @@ def run_segmenter(src_path: str, save_path: str, deconvolution: bool):
         bg_output_queue = Queue()
         Thread(target=run_reader, args=([(f, i) for i, f in enumerate(batch)], reader_output, 8, settings.resize)).start()
         run_bg_correction(reader_output, bg_output_queue, 6, None)                              # :239-241
-        run_detection(bg_output_queue, settings, 8, len(batch), None)                           # :254
+        if deconvolution:                                                                       # :243-249
+            from .deconv_bridge import run_deconvolution
+            deconv_output_queue = Queue()
+            Thread(target=run_deconvolution, args=(bg_output_queue, deconv_output_queue, len(batch), 1, model)).start()
+        else:
+            deconv_output_queue = bg_output_queue
+        run_detection(deconv_output_queue, settings, 8, len(batch), None)                       # :254
         print(f"Time per image: {(time.perf_counter() - start) / len(batch)}")                  # :256-258
     print("finished segmentation...")

@@ -160,3 +160,61 @@ def test_abi_error_paths_return_codes_and_text():
     cleaned, ms, valid = seg.bgcorrect(torch.full((12, 64, 128), 7, dtype=torch.uint8, device="cuda"))
     assert valid.sum() == 0 and np.allclose(ms[:, 0], 7.0)
     seg.close()
+
+
+def test_deconvolution_hand_off_on_device(gpu_seg_factory):
+    """segmenter.py with deconvolution=True, frames resident on the device: background correction -> a stand-in network
+    (the reference's LUCYD weights do not travel) -> detection with Crops/ cut from the background-corrected image and
+    Deconv_crops/ + properties from the network output.  The oracle gets the same network output computed on the host
+    the way deconvolution.py does (float64 division, float32 model, * 255, astype(uint8))."""
+    import torch
+    from imageprocessing_amd import deconv_bridge, synth
+    H, W, n = 192, 256, 14
+    seg = gpu_seg_factory(H, W)
+    cfg = dict(synth.CONFIGS["pisco"]); cfg.update(per_frame=9, dmin=20, dmax=300)
+    objs, off = synth.make_objects(n, H, W, 4, **cfg)
+    stack = synth.render(n, H, W, 4, objs, off)
+    stack[5] = 33                                                        # corrupt frame: skips the network
+    mask = helpers.make_disk(H, W, 90)
+
+    def model(x):                                                        # contrast stretch + a little blur, float32
+        k = torch.tensor([[0.05, 0.1, 0.05], [0.1, 0.4, 0.1], [0.05, 0.1, 0.05]], dtype=torch.float32, device=x.device)
+        y = torch.nn.functional.conv2d(x, k[None, None], padding=1)
+        return (torch.clamp(1.25 * y - 0.2, 0.0, 1.0), None, None)       # a tuple like LUCYD's (y_hat, k, update)
+
+    labels = torch.empty((n, H, W), dtype=torch.int32, device="cuda")
+    cleaned, deconv, ms, valid, tab = deconv_bridge.process_with_deconvolution(
+        seg, torch.from_numpy(stack).cuda(), model, mask=torch.from_numpy(mask).cuda(), labels=labels, fetch_crops=True,
+        min_area_to_save=150.0)
+    # host side, as the reference does it (deconvolution.py:70-100); the stand-in network runs on the GPU in both cases
+    items = helpers.oracle_bgcorrect(stack)
+    deconv_items = []
+    for i, it in enumerate(items):
+        if isinstance(it[1], list):
+            deconv_items.append(it)
+            continue
+        x_t = torch.from_numpy(it[1] / 255).cuda().unsqueeze(0).unsqueeze(0)
+        y = model(x_t.float())[0].detach().cpu().numpy()[0, 0]
+        d = (y * 255).astype(np.uint8)
+        assert np.array_equal(deconv[i].cpu().numpy(), d), f"frame {i}: network input / output conversion"
+        deconv_items.append((it[0], d, it[2], it[3]))
+    dets = helpers.oracle_detect(deconv_items, mask, min_area_to_save=150)
+    assert tab.saved.sum() > 0
+    helpers.compare_table(tab, dets, H, W, labels=labels.cpu().numpy())
+    # the queue-based stage with the reference's signature gives the same frames
+    from queue import Queue
+    qi, qo = Queue(), Queue()
+    for it in items:
+        qi.put(it)
+    deconv_bridge.run_deconvolution(qi, qo, len(items), 4, model)
+    got = {}
+    while not qo.empty():
+        corr, d, mean, fn = qo.get()
+        got[fn] = (corr, d)
+    assert len(got) == n
+    for i, it in enumerate(items):
+        corr, d = got[it[3]]
+        if isinstance(it[1], list):
+            assert isinstance(d, list)
+        else:
+            assert torch.equal(d, deconv[i]) and torch.equal(corr, cleaned[i])
