@@ -872,15 +872,20 @@ __global__ __launch_bounds__(1024) void k_rank(SegState S, double min_seg, doubl
 
 // one row per kept object, ordered (frame, c); c counts from the LAST external root (detection.py:222)
 __global__ void k_emit(SegState S, int nfg, double min_seg, double min_save, const uint32_t *ftot3, const uint32_t *rowbase,
-                       const uint32_t *savedbase, RowsDev R, int32_t *objlabel, int32_t *objflag, int32_t *saved_row)
+                       const uint32_t *savedbase, RowsDev R, int32_t *objlabel, int32_t *objflag, int32_t *saved_row,
+                       int32_t *runlabel)
 {
     size_t g = GTID;
     if (g >= (size_t)nfg) return;
     int r = (int)g;
     objflag[r] = 0;
     objlabel[r] = 0;
-    if (!is_ext_root(S, r)) return;
     int f = (int)(S.run_fy[r] >> 16);
+    {   // label-map value of this run: the label of its external component, 0 for components nested in holes
+        const int E = S.ext[r];
+        runlabel[r] = (S.fg_parent[r] == E) ? (int)ftot3[f * 3] - S.extrank[E] : 0;
+    }
+    if (!is_ext_root(S, r)) return;
     int next = (int)ftot3[f * 3], nkept = (int)ftot3[f * 3 + 1], nsaved = (int)ftot3[f * 3 + 2];
     int label = next - S.extrank[r];
     objlabel[r] = label;
@@ -904,13 +909,6 @@ __global__ void k_emit(SegState S, int nfg, double min_seg, double min_save, con
 // Otherwise the wave works together: the row's runs and their labels are loaded one per lane, the runs that meet the
 // span are broadcast one after the other (typically one or two) and every lane takes what falls on its pixels.
 typedef int32_t i32x4_t __attribute__((ext_vector_type(4)));
-__global__ void k_run_labels(SegState S, int nfg, const int32_t *__restrict__ objlabel, int32_t *__restrict__ runlabel)
-{
-    const size_t g = GTID;
-    if (g >= (size_t)nfg) return;
-    const int E = S.ext[g];
-    runlabel[g] = (S.fg_parent[g] == E) ? objlabel[E] : 0;  // components nested in holes keep 0
-}
 // grid = (ceil(W / 1024), H, frames): row and frame come from the block index (no divisions; at one KiB per wave the
 // kernel only streams at full rate while a wave spends a few dozen instructions)
 __global__ __launch_bounds__(256) void k_label_fill(SegState S, const int32_t *__restrict__ runlabel, int32_t *__restrict__ labels)
@@ -1667,7 +1665,7 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
     ENSURE(ctx->bg_parent, (size_t)nbg * 4); ENSURE(ctx->bg_left, (size_t)nbg * 4);
     ENSURE(ctx->minx, cap * 4); ENSURE(ctx->maxx, cap * 4); ENSURE(ctx->maxy, cap * 4);
     ENSURE(ctx->area2, cap * 4); ENSURE(ctx->extrank, cap * 4); ENSURE(ctx->keptrank, cap * 4); ENSURE(ctx->savedrank, cap * 4);
-    ENSURE(ctx->objlabel, cap * 4); ENSURE(ctx->objflag, cap * 4);
+    ENSURE(ctx->objlabel, cap * 4); ENSURE(ctx->objflag, cap * 4); ENSURE(ctx->runlabel, cap * 4);
     S.run_x = (uint32_t *)ctx->run_x.p; S.run_fy = (uint32_t *)ctx->run_fy.p;
     S.fg_parent = (int32_t *)ctx->fg_parent.p; S.ext = (int32_t *)ctx->ext.p; S.gapl = (int32_t *)ctx->gapl.p;
     S.bg_parent = (int32_t *)ctx->bg_parent.p; S.bg_left = (int32_t *)ctx->bg_left.p;
@@ -1716,7 +1714,8 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
     long long *totals = (long long *)ctx->totals.p;
     if (nfg > 0) {
         hipLaunchKernelGGL(k_emit, dim3(nblocks(nfg)), dim3(256), 0, st, S, nfg, min_seg, min_save, (const uint32_t *)ftot3,
-                           (const uint32_t *)rowbase, (const uint32_t *)savedbase, R, objlabel, objflag, saved_row);
+                           (const uint32_t *)rowbase, (const uint32_t *)savedbase, R, objlabel, objflag, saved_row,
+                           (int32_t *)ctx->runlabel.p);
         hipLaunchKernelGGL(k_saved_geo, dim3(nblocks(nfg)), dim3(256), 0, st, (const uint32_t *)(savedbase + n),
                            (const int32_t *)saved_row, R, geo, sz, totals);
     }
@@ -1729,8 +1728,6 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
     // (running the label fill on a second stream next to the crop / property kernels was measured: the fill takes 2.0 ms
     // instead of 0.93 ms when it shares the CUs, a net loss)
     if (labels) {
-        ENSURE(ctx->runlabel, cap * 4);
-        if (nfg > 0) hipLaunchKernelGGL(k_run_labels, dim3(nblocks(nfg)), dim3(256), 0, st, S, nfg, (const int32_t *)objlabel, (int32_t *)ctx->runlabel.p);
         hipLaunchKernelGGL(k_label_fill, dim3((W + 1023) / 1024, H, n), dim3(256), 0, st, S,
                            (const int32_t *)ctx->runlabel.p, labels);
         HIPCHK(hipGetLastError());
