@@ -395,8 +395,8 @@ __global__ __launch_bounds__(256, 4) void k_bg_stream(const uint8_t *__restrict_
     if (mask) { uint2 m = *(const uint2 *)(mask + strip * 8); E.inm = make_uint2(eq255_4(m.x), eq255_4(m.y)); }
     E.act = act ? 0xffffffffu : 0u;
     E.inm.x &= E.act; E.inm.y &= E.act;
-    const int t1 = thr + 1;                                 // pixel > thr  <=>  pixel >= thr + 1
-    const bool thr_ok = t1 >= 1 && t1 <= 255;               // threshold outside 0..254: no pixel passes
+    const int t1 = thr + 1 > 0 ? thr + 1 : 0;               // pixel > thr  <=>  pixel >= thr + 1 (negative thr: every pixel)
+    const bool thr_ok = t1 <= 255;                          // thr >= 255: no pixel passes
     E.kadd = thr_ok ? (uint32_t)(0x8000 - t1) * 0x00010001u : 0u;
     E.inm8 = thr_ok ? (gather4(E.inm.x & 0x80808080u) | (gather4(E.inm.y & 0x80808080u) << 4)) : 0u;
     E.nwaves = gridDim.x * 4; E.wave = blockIdx.x * 4 + (threadIdx.x >> 6);

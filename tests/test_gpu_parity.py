@@ -238,3 +238,61 @@ def test_rows_wider_than_one_wave_of_words(gpu_seg_factory):
         assert np.array_equal(cl[i], it[1])
         thr = (255 - it[1]) > 120
         assert tab2.frame_n_contours[i] == len(helpers.cv_ref.findContours(thr.astype(np.uint8), 0, 2)[0])
+
+
+@pytest.mark.parametrize("n_bg_imgs,n,generic", [(2, 9, "0"), (8, 20, "0"), (3, 16, "0"), (6, 30, "1")])
+def test_other_windows_and_the_generic_kernel(monkeypatch, n_bg_imgs, n, generic):
+    """Windows other than the reference's 12 frames (bg_size = 6) and PSEG_BG_GENERIC=1 take the re-reading kernel; the
+    fused path, its masked statistics and the part / halo form must agree with the oracle there too."""
+    import torch
+    from imageprocessing_amd.engine import Segmenter
+    monkeypatch.setenv("PSEG_BG_GENERIC", generic)
+    H, W = 64, 128
+    seg = Segmenter(H, W, max_frames=n, device=0)
+    rng = np.random.default_rng(7 * n_bg_imgs + n)
+    stack = rng.integers(0, 256, (n, H, W), dtype=np.uint8)
+    mask = helpers.make_disk(H, W, 28)
+    images = [(stack[i], f"img_{i:05d}.png") for i in range(n)]
+    items = [helpers.ref.correct_img(i, images, n_bg_imgs) for i in range(n)]
+    dev, dmask = torch.from_numpy(stack).cuda(), torch.from_numpy(mask).cuda()
+    cleaned, ms, valid, tab = seg.process(dev, n_bg_imgs=n_bg_imgs, mask=dmask, threshold=90)
+    cl = cleaned.cpu().numpy()
+    for i, it in enumerate(items):
+        assert np.array_equal(cl[i], it[1]), f"frame {i}"
+        corr = (255 - it[1])[mask == 255]
+        np.testing.assert_allclose([tab.frame_mean[i], tab.frame_std[i]], [corr.mean(), corr.std()], rtol=1e-9)
+        thr = ((255 - it[1]) > 90) & (mask == 255)
+        assert tab.frame_n_contours[i] == len(helpers.cv_ref.findContours(thr.astype(np.uint8), 0, 2)[0])
+    # the leading part of the batch with its forward halo of 2 * n_bg_imgs - 1 frames
+    ne = n - 2 * n_bg_imgs - 1
+    if ne >= 1:
+        c2, ms2, v2, tab2 = seg.process(dev[:ne + 2 * n_bg_imgs - 1], n_bg_imgs=n_bg_imgs, mask=dmask, threshold=90, n_emit=ne)
+        assert torch.equal(c2, cleaned[:ne])
+        assert np.array_equal(tab2.frame_n_contours, tab.frame_n_contours[:ne])
+    seg.close()
+
+
+def test_threshold_extremes_and_all_foreground(gpu_seg_factory):
+    import torch
+    H, W, n = 128, 192, 12
+    seg = gpu_seg_factory(H, W)
+    rng = np.random.default_rng(2)
+    stack = rng.integers(0, 256, (n, H, W), dtype=np.uint8)
+    dev = torch.from_numpy(stack).cuda()
+    for thr, expect_empty in ((255, True), (254, False), (0, False), (-1, False), (-300, False), (400, True)):
+        tab = seg.process(dev, threshold=thr)[3]
+        cleaned = seg.bgcorrect(dev)[0].cpu().numpy()
+        for f in range(n):
+            want = len(helpers.cv_ref.findContours(((255 - cleaned[f].astype(np.int32)) > thr).astype(np.uint8), 0, 2)[0])
+            assert tab.frame_n_contours[f] == want, (thr, f)
+        assert (tab.n_rows == 0) or not expect_empty
+    # a frame that is foreground everywhere: one object, its crop is the whole frame
+    cl = np.zeros((2, H, W), np.uint8)
+    cl[1] = 255
+    cl[1, 40:60, 50:90] = 0
+    items = [(cl[f], cl[f], [100.0, 50.0], f"a_{f}.png") for f in range(2)]
+    dets = helpers.oracle_detect(items, None, mask_img=False)
+    labels = torch.empty((2, H, W), dtype=torch.int32, device="cuda")
+    tab = seg.detect(torch.from_numpy(cl).cuda(), labels=labels, fetch_crops=True)
+    helpers.compare_table(tab, dets, H, W, labels=labels.cpu().numpy())
+    assert (tab.w[0], tab.h[0]) == (W, H) and tab.area[0] == (W - 1) * (H - 1)
