@@ -76,6 +76,8 @@ struct pseg_ctx {
     HostBuf h_frame_row_offset, h_frame_n_contours, h_frame_valid, h_frame_mean, h_frame_std, h_area, h_saved8, h_props;
     int64_t crop_bytes = 0;
     int n_saved = 0;
+    // host views of the last table (page-locked tail buffer): rows [10][t_hr], saved_row, crop_off
+    const int32_t *t_rows = nullptr, *t_saved_row = nullptr; const int64_t *t_crop_off = nullptr; size_t t_hr = 1;
 };
 
 static int fail(pseg_ctx *c, int code, const std::string &msg)
@@ -1817,6 +1819,7 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
         const int i = h_saved_row[s];
         props_from_sums(h_sums + (size_t)s * PSEG_NSUMS, hrows[6 * hr + i], hrows[7 * hr + i], h_props + (size_t)s * PSEG_NPROPS);
     }
+    ctx->t_rows = hrows; ctx->t_saved_row = h_saved_row; ctx->t_crop_off = h_crop_off; ctx->t_hr = hr;
     if (out) {
         memset(out, 0, sizeof(*out));
         out->n_frames = n; out->n_rows = n_rows; out->n_saved = n_saved; out->crop_bytes = ctx->crop_bytes;
@@ -1910,6 +1913,109 @@ extern "C" int pseg_fetch_crops(pseg_ctx *ctx, uint8_t *raw, uint8_t *masked, ui
     if (masked) HIPCHK(hipMemcpyAsync(masked, ctx->crops_masked.p, nb, hipMemcpyDeviceToHost, ctx->stream));
     if (mask) HIPCHK(hipMemcpyAsync(mask, ctx->crops_mask.p, nb, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    return PSEG_OK;
+}
+
+// ---- classifier input tensors straight from the packed crops ---------------------------------------
+// Classify_ViT.py:92-145 without the random rotation: the crop (grey, replicated to RGB) is resized so that its longer edge
+// becomes 224 (the other edge int-truncated), padded with 255 to 224 x 224 (centred, the odd pixel right / bottom), scaled
+// to [0,1] and normalised with mean = std = 0.5.  torchvision's resize of a PIL image is PIL's Image.resize(BILINEAR); its
+// algorithm (Resample.c) is restated exactly: per output sample the filter support widens with the scale, the weights
+// are normalised in double precision (no fused multiply-adds: the C library is compiled without them), converted to
+// 22-bit fixed point, and the two passes (horizontal, then vertical) round to uint8 in between.
+#define VIT_SIZE 224
+__device__ __forceinline__ int pil_resample_1d(const uint8_t *src, size_t stride, int in_size, int out_size, int xx)
+{
+    const double scale = __ddiv_rn((double)in_size, (double)out_size);
+    const double filterscale = scale < 1.0 ? 1.0 : scale;
+    const double support = filterscale;                     // bilinear: support 1.0 * filterscale
+    const double center = __dmul_rn(__dadd_rn((double)xx, 0.5), scale);
+    const double ss = __ddiv_rn(1.0, filterscale);
+    int xmin = (int)__dadd_rn(__dsub_rn(center, support), 0.5);
+    if (xmin < 0) xmin = 0;
+    int xmax = (int)__dadd_rn(__dadd_rn(center, support), 0.5);
+    if (xmax > in_size) xmax = in_size;
+    xmax -= xmin;
+    auto weight = [&](int x) {
+        double t = __dmul_rn(__dadd_rn(__dsub_rn((double)(x + xmin), center), 0.5), ss);
+        if (t < 0.0) t = -t;
+        return t < 1.0 ? __dsub_rn(1.0, t) : 0.0;
+    };
+    double ww = 0.0;
+    for (int x = 0; x < xmax; x++) ww = __dadd_rn(ww, weight(x));
+    int acc = 1 << 21;                                      // PRECISION_BITS = 22
+    for (int x = 0; x < xmax; x++) {
+        double k = weight(x);
+        if (ww != 0.0) k = __ddiv_rn(k, ww);
+        const int kk = (int)__dadd_rn(0.5, __dmul_rn(k, 4194304.0));
+        acc += (int)src[(size_t)(x + xmin) * stride] * kk;
+    }
+    acc >>= 22;
+    return acc < 0 ? 0 : (acc > 255 ? 255 : acc);
+}
+// par[k*8] = crop offset lo, hi, w, h, new_w, new_h, tmp offset lo, hi
+__global__ __launch_bounds__(256) void k_vit_horizontal(const uint8_t *__restrict__ plane, const int32_t *__restrict__ par, uint8_t *__restrict__ tmp)
+{
+    const int32_t *q = par + 8 * blockIdx.y;
+    const long long off = ((long long)q[1] << 32) | (uint32_t)q[0], toff = ((long long)q[7] << 32) | (uint32_t)q[6];
+    const int w = q[2], h = q[3], nw = q[4];
+    const int total = h * nw;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < total; p += gridDim.x * 256) {
+        const int yy = p / nw, xx = p - yy * nw;
+        tmp[toff + p] = (uint8_t)pil_resample_1d(plane + off + (size_t)yy * w, 1, w, nw, xx);
+    }
+}
+__global__ __launch_bounds__(256) void k_vit_vertical(const int32_t *__restrict__ par, const uint8_t *__restrict__ tmp, float *__restrict__ out)
+{
+    const int32_t *q = par + 8 * blockIdx.y;
+    const long long toff = ((long long)q[7] << 32) | (uint32_t)q[6];
+    const int h = q[3], nw = q[4], nh = q[5];
+    const int left = (VIT_SIZE - nw) / 2, top = (VIT_SIZE - nh) / 2;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= VIT_SIZE * VIT_SIZE) return;
+    const int oy = p / VIT_SIZE, ox = p - oy * VIT_SIZE;
+    int v = 255;                                            // padding colour
+    if (nw > 0 && nh > 0 && ox >= left && ox < left + nw && oy >= top && oy < top + nh)
+        v = pil_resample_1d(tmp + toff + (ox - left), (size_t)nw, h, nh, oy - top);
+    const float t = ((float)v / 255.0f - 0.5f) / 0.5f;      // ToTensor, Normalize(0.5, 0.5)
+    float *o = out + (size_t)blockIdx.y * 3 * VIT_SIZE * VIT_SIZE + p;
+    o[0] = t; o[VIT_SIZE * VIT_SIZE] = t; o[2 * VIT_SIZE * VIT_SIZE] = t;
+}
+extern "C" int pseg_vit_tensors(pseg_ctx *ctx, int plane, int first, int count, float *out, uint8_t *valid)
+{
+    if (!ctx) return PSEG_ERR_ARG;
+    if (!out || plane < 0 || plane > 2 || first < 0 || count < 0 || first + count > ctx->n_saved)
+        return fail(ctx, PSEG_ERR_ARG, "pseg_vit_tensors: bad plane or object range (objects are the saved ones of the last detection)");
+    if (count == 0) return PSEG_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    std::vector<int32_t> par((size_t)count * 8);
+    long long tmp_total = 0;
+    int max_pix = 1;
+    for (int k = 0; k < count; k++) {
+        const int s = first + k, i = ctx->t_saved_row[s];
+        const int w = ctx->t_rows[6 * ctx->t_hr + i], h = ctx->t_rows[7 * ctx->t_hr + i];
+        const long long off = ctx->t_crop_off[s];
+        const double scale_factor = 224.0 / (double)(w > h ? w : h);           // Classify_ViT.py:92-106, Python float arithmetic
+        const int nw = (int)((double)w * scale_factor), nh = (int)((double)h * scale_factor);
+        int32_t *q = &par[(size_t)k * 8];
+        q[0] = (int32_t)(off & 0xffffffffLL); q[1] = (int32_t)(off >> 32); q[2] = w; q[3] = h; q[4] = nw; q[5] = nh;
+        q[6] = (int32_t)(tmp_total & 0xffffffffLL); q[7] = (int32_t)(tmp_total >> 32);
+        if (valid) valid[k] = (nw > 0 && nh > 0) ? 1 : 0;                       // F.resize raises for an empty size: the reference skips the image
+        if (nw > 0 && nh > 0) { tmp_total += (long long)h * nw; if (h * nw > max_pix) max_pix = h * nw; }
+        else { q[4] = 0; q[5] = 0; }
+    }
+    ENSURE(ctx->rp_small, par.size() * 4);
+    ENSURE(ctx->rp_scratch, (size_t)tmp_total + 64);
+    HIPCHK(hipMemcpyAsync(ctx->rp_small.p, par.data(), par.size() * 4, hipMemcpyHostToDevice, st));
+    const uint8_t *pl = (const uint8_t *)(plane == 0 ? ctx->crops_raw.p : plane == 1 ? ctx->crops_masked.p : ctx->crops_mask.p);
+    unsigned gx = nblocks((size_t)max_pix);
+    if (gx > 256) gx = 256;
+    hipLaunchKernelGGL(k_vit_horizontal, dim3(gx, count), dim3(256), 0, st, pl, (const int32_t *)ctx->rp_small.p, (uint8_t *)ctx->rp_scratch.p);
+    hipLaunchKernelGGL(k_vit_vertical, dim3(nblocks((size_t)VIT_SIZE * VIT_SIZE), count), dim3(256), 0, st, (const int32_t *)ctx->rp_small.p,
+                       (const uint8_t *)ctx->rp_scratch.p, out);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
     return PSEG_OK;
 }
 

@@ -135,6 +135,7 @@ class Segmenter:
 
     def _table(self, t, fetch_crops):
         n, nr, ns = t.n_frames, t.n_rows, t.n_saved
+        self._n_saved = ns
         tab = ObjectTable(
             n_frames=n,
             frame_row_offset=_np(t.frame_row_offset, n + 1, np.int32), frame_n_contours=_np(t.frame_n_contours, n, np.int32),
@@ -204,6 +205,28 @@ class Segmenter:
         self._chk(self.L.pseg_regionprops(self.h, mask.data_ptr(), img.data_ptr(), int(h), int(w), int(mask.stride(0)),
                                           props.ctypes.data, None))
         return props
+
+    def vit_tensors(self, first=0, count=None, plane="masked", out=None):
+        """Classifier inputs of saved objects [first, first+count) of the last detection, straight from the packed device
+        crops: what Classify_ViT.py:92-145 (resize the longer edge to 224 with PIL's bilinear filter, pad with white,
+        ToTensor, Normalize(0.5, 0.5)) makes of the PNG the reference would have written, minus the random rotation.
+        Returns (float32 CUDA tensor [count, 3, 224, 224], valid uint8[count]); valid 0 = a crop so thin that its resized
+        short edge is 0 px (the reference logs the error and skips the file)."""
+        import torch
+        ns = self.n_saved_last()
+        count = ns - first if count is None else int(count)
+        if out is None:
+            out = torch.empty((count, 3, 224, 224), dtype=torch.float32, device=f"cuda:{self.device}")
+        if out.dtype != torch.float32 or not out.is_contiguous() or out.numel() != count * 3 * 224 * 224 or out.device.index != self.device:
+            raise PsegError("out must be a contiguous float32 tensor [count, 3, 224, 224] on the segmenter's GPU")
+        valid = np.zeros(max(count, 1), np.uint8)
+        torch.cuda.current_stream(out.device).synchronize()
+        self._chk(self.L.pseg_vit_tensors(self.h, {"raw": 0, "masked": 1, "mask": 2}[plane], int(first), count, out.data_ptr(),
+                                          valid.ctypes.data))
+        return out, valid[:count]
+
+    def n_saved_last(self):
+        return self._n_saved
 
     def synth_frames(self, n, seed, objs, frame_obj_off, frame0=0, out=None):
         import torch

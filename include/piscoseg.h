@@ -126,6 +126,16 @@ int pseg_fetch_crops(pseg_ctx *ctx, uint8_t *raw, uint8_t *masked, uint8_t *mask
 int pseg_regionprops(pseg_ctx *ctx, const uint8_t *mask, const uint8_t *img, int h, int w, int stride,
                      double *props, int64_t *sums_out);
 
+/* SURVEY.md 8(f) N3 -- classifier inputs of saved objects [first, first+count) of the context's last detection, read from
+ * the packed device crops (plane 0 = raw, 1 = masked: the Deconv_crops/ images the classifier is pointed at, 2 = mask).
+ * Replaces, for crops that never left the GPU, Image.open(...).convert('RGB') + get_pad_transform's ResizeAndPad((224, 224))
+ * + ToTensor + Normalize(0.5, 0.5) (Classify_ViT.py:92-145; the RandomRotation(180, fill=255) of that pipeline is random
+ * and left to the caller): longer edge -> 224 with PIL's bilinear resize (int-truncated other edge), centred white
+ * padding (odd pixel right / bottom), (p/255 - 0.5)/0.5 in float32, grey replicated to 3 channels.
+ * out [dev] float[count][3][224][224]; valid [host] u8[count] or NULL: 0 where the resized short edge would be 0 px
+ * (the reference's load raises and the file is skipped, Classify_ViT.py:170-176; the tensor is then all padding). */
+int pseg_vit_tensors(pseg_ctx *ctx, int plane, int first, int count, float *out, uint8_t *valid);
+
 /* cv.circle(mask, (W/2, H/2), radius, 255, -1) on the device (detection.py:315-326). mask [dev] u8[H][W]. */
 int pseg_disk_mask(pseg_ctx *ctx, int radius, uint8_t *mask);
 

@@ -218,3 +218,72 @@ def test_deconvolution_hand_off_on_device(gpu_seg_factory):
             assert isinstance(d, list)
         else:
             assert torch.equal(d, deconv[i]) and torch.equal(corr, cleaned[i])
+
+
+def _pil_classifier_input(crop):
+    """Classify_ViT.py:92-145 on one grey crop with PIL and numpy (torchvision is absent here: F.resize of a PIL image is
+    Image.resize(BILINEAR), Pad pastes onto a filled canvas, ToTensor divides by 255 in float32, Normalize subtracts and
+    divides by 0.5), without the random rotation.  Returns None where the reference skips the image."""
+    from PIL import Image
+    im = Image.fromarray(crop).convert("RGB")
+    ow, oh = im.size
+    scale_factor = 224 / max(ow, oh)
+    nw, nh = int(ow * scale_factor), int(oh * scale_factor)
+    try:
+        r = im.resize((nw, nh), Image.BILINEAR)
+    except ValueError:
+        return None
+    left, top = (224 - nw) // 2, (224 - nh) // 2
+    canvas = Image.new("RGB", (224, 224), (255, 255, 255))
+    canvas.paste(r, (left, top))
+    a = np.asarray(canvas).transpose(2, 0, 1).astype(np.float32)
+    return (a / np.float32(255) - np.float32(0.5)) / np.float32(0.5)
+
+
+def test_classifier_tensors_match_pil(gpu_seg_factory):
+    """pseg_vit_tensors on the packed device crops against PIL's resize of the fetched crops, bit for bit
+    (uint8 resampling is integer arithmetic; the float32 normalisation is two IEEE operations).  Crops include upscaled
+    and downscaled ones, wide, tall, and one so thin that the reference skips it."""
+    import torch
+    H, W, n = 512, 1024, 3
+    seg = gpu_seg_factory(H, W)
+    rng = np.random.default_rng(5)
+    cleaned = np.full((n, H, W), 255, np.uint8)
+    yy, xx = np.mgrid[0:H, 0:W]
+    boxes = [(0, 20, 30, 25, 40), (0, 100, 100, 300, 130), (0, 10, 500, 40, 450), (0, 450, 20, 5, 600), (0, 400, 700, 100, 23),
+             (1, 50, 60, 224, 224), (1, 300, 300, 2, 700), (1, 100, 500, 37, 91), (2, 5, 5, 500, 1000)]
+    for f, y, x, h, w in boxes:
+        blob = ((yy[y:y + h, x:x + w] - (y + h / 2)) / (h / 2)) ** 2 + ((xx[y:y + h, x:x + w] - (x + w / 2)) / (w / 2)) ** 2 <= 1.0
+        if h <= 5:
+            blob[:] = True
+        tex = rng.integers(0, 200, (h, w), dtype=np.uint8)
+        cleaned[f, y:y + h, x:x + w] = np.where(blob, tex, 255)
+    tab = seg.detect(torch.from_numpy(cleaned).cuda(), fetch_crops=True, min_area_to_save=400.0)
+    ns = len(tab.saved_row)
+    assert ns >= 8
+    for plane in ("masked", "raw"):
+        out, valid = seg.vit_tensors(plane=plane)
+        assert out.shape == (ns, 3, 224, 224)
+        got = out.cpu().numpy()
+        n_skipped = 0
+        for s in range(ns):
+            want = _pil_classifier_input(tab.crop(s, plane))
+            if want is None:
+                assert valid[s] == 0
+                n_skipped += 1
+                continue
+            assert valid[s] == 1
+            assert np.array_equal(got[s], want), (plane, s, tab.crop(s, plane).shape, np.abs(got[s] - want).max())
+        assert n_skipped == 1
+    # a sub-range into a caller's buffer
+    buf = torch.zeros((2, 3, 224, 224), dtype=torch.float32, device="cuda")
+    seg.vit_tensors(first=3, count=2, out=buf)
+    assert np.array_equal(buf.cpu().numpy(), got_range(seg, 3, 2))
+    from imageprocessing_amd.engine import PsegError
+    with pytest.raises(PsegError, match="range"):
+        seg.vit_tensors(first=ns - 1, count=2)
+
+
+def got_range(seg, first, count):
+    out, _ = seg.vit_tensors(plane="masked")
+    return out[first:first + count].cpu().numpy()
