@@ -287,3 +287,34 @@ def test_classifier_tensors_match_pil(gpu_seg_factory):
 def got_range(seg, first, count):
     out, _ = seg.vit_tensors(plane="masked")
     return out[first:first + count].cpu().numpy()
+
+
+def test_crop_dataframe_from_device_table_equals_csv_round_trip(tmp_path):
+    """the crop table built from the in-memory object table equals gen_crop_df (restated in
+    oracle/ecotaxa_ref.py) reading back the CSV files the detection stage wrote for the same batch."""
+    import pandas as pd
+    from imageprocessing_amd import bg_correction, detection, reader, synth, tables
+    from oracle import ecotaxa_ref
+    H = W = 256
+    n = 13
+    objs, off = synth.make_objects(n, H, W, 17, per_frame=9, dmin=40, dmax=700)
+    stack = synth.render(n, H, W, 17, objs, off)
+    stack[2] = 17                                            # corrupt frame
+    names = [f"20240115-0915{59 - i:02d}123_{20.5 + i:06.2f}bar_{9.75 + i / 4:.2f}C.png" for i in range(n)]
+    out = reader.ReaderOutput(n)
+    for i in range(n):
+        out.add_output(stack[i], names[i], i)
+    q = Queue()
+    bg_correction.run_bg_correction(out, q, 6, None).join()
+    items = [q.get() for _ in range(n)]
+    dirs = {k: str(tmp_path / k) for k in ("Data", "Crops", "Deconv_crops", "Masks", "Images")}
+    for d in dirs.values():
+        os.makedirs(d)
+    settings = detection.DetectionSettings(dirs["Data"], dirs["Crops"], dirs["Deconv_crops"], dirs["Masks"], dirs["Images"],
+                                           400, 10, 1, False, False, True, False, True, True, 120)
+    tab = detection.detect_batch(items, settings, helpers.make_disk(H, W, 120), n_writers=4)
+    good = [it for it in items if not isinstance(it[1], list)]
+    got = tables.crop_dataframe(tab, [it[3] for it in good], [it[2] for it in good], dirs["Data"])
+    want, _ = ecotaxa_ref.gen_crop_df(dirs["Data"], False, 0)
+    assert len(want) > 10 and list(got.columns) == list(want.columns)
+    pd.testing.assert_frame_equal(got, want, check_exact=False, rtol=1e-12, atol=0)
