@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libpiscoseg.so")
+LIB_PATH = os.environ.get("PSEG_LIB") or os.path.join(HERE, "libpiscoseg.so")   # PSEG_LIB: another build of the same library
 CSRC = os.path.join(HERE, "csrc")
 
 NPROPS = 32

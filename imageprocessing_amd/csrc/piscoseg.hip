@@ -325,7 +325,8 @@ __device__ __forceinline__ void bg_emit(const BgEmit &E, uint2 img, Px8 c, Px8 b
     uint8_t *pc = real ? E.cleaned + (size_t)s * E.P : E.t_cleaned;          // wave-uniform bases, 32-bit lane offsets
     uint8_t *pb = real ? E.bits8 + (size_t)s * (E.P / 8) : E.t_bits8;
     uint4 *pp = en ? E.partials + (size_t)s * E.nwaves : E.t_partials;
-    *(uint2 *)(pc + E.off8) = make_uint2(~corr.x, ~corr.y);
+    // streamed out: a plain store would leave 1.3 GB of dirty lines to drain from L2 under the kernels that follow
+    { u32x2_t cv; cv.x = ~corr.x; cv.y = ~corr.y; __builtin_nontemporal_store(cv, (u32x2_t *)(pc + E.off8)); }
     uint2 cm = make_uint2(corr.x & E.inm.x, corr.y & E.inm.y);
     img.x &= E.act; img.y &= E.act;
     uint32_t s0 = __builtin_amdgcn_sad_u8(img.x, 0u, __builtin_amdgcn_sad_u8(img.y, 0u, 0u));
