@@ -86,6 +86,30 @@ __global__ __launch_bounds__(256) void kK(const uint4 *__restrict__ a, uint4 *__
         if (i < per_frame) b[(size_t)f * per_frame + i] = a[(size_t)f * per_frame + i];
     }
 }
+// W: the window shape without a frame loop: a thread makes G consecutive output frames of one 16-byte (or 8-byte) strip
+// from G + 11 input frames (11 of them read before by neighbours in time: cache hits), blocks ordered tile-major, then
+// frame group, then strip inside the tile.  Output = max over the window (stand-in arithmetic).
+template <typename T, int G>
+__global__ __launch_bounds__(256) void kW(const T *__restrict__ a, T *__restrict__ b, size_t per_frame, int nframes, int strips_per_tile)
+{
+    const int ngroups = (nframes - 11) / G;                   // the tail frames are left out of this probe
+    const unsigned bpt = strips_per_tile / 256;               // blocks per tile and frame group
+    const unsigned tile = blockIdx.x / (bpt * ngroups), r = blockIdx.x % (bpt * ngroups);
+    const unsigned g = r / bpt, sb = r % bpt;
+    const size_t i = (size_t)tile * strips_per_tile + sb * 256 + threadIdx.x;
+    if (i >= per_frame) return;
+    T v[G + 11];
+#pragma unroll
+    for (int k = 0; k < G + 11; k++) v[k] = a[(size_t)(g * G + k) * per_frame + i];
+#pragma unroll
+    for (int j = 0; j < G; j++) {
+        T m = v[j];
+#pragma unroll
+        for (int k = 1; k < 12; k++) { m.x = m.x > v[j + k].x ? m.x : v[j + k].x; m.y = m.y > v[j + k].y ? m.y : v[j + k].y; }
+        __builtin_nontemporal_store(m.x, &b[(size_t)(g * G + j) * per_frame + i].x);
+        __builtin_nontemporal_store(m.y, &b[(size_t)(g * G + j) * per_frame + i].y);
+    }
+}
 int main()
 {
     const size_t P = 2560 * 2560, n = 200, bytes = P * n;
@@ -117,10 +141,21 @@ int main()
     run("F one-shot, frame-fastest order", [&] { hipLaunchKernelGGL(kF, dim3((unsigned)(1600 * n)), dim3(256), 0, 0, (const uint4 *)a, (uint4 *)b, pf16, (int)n); });
     run("G strip 4KiB, non-temporal", [&] { hipLaunchKernelGGL(kG, dim3(1600), dim3(256), 0, 0, (const uint4 *)a, (uint4 *)b, pf16, (int)n); });
     run("H strip 16KiB (1024 threads)", [&] { hipLaunchKernelGGL(kH, dim3(400), dim3(1024), 0, 0, (const uint4 *)a, (uint4 *)b, pf16, (int)n); });
+    {
+        auto w = [&](const char *name, auto kern, size_t pf, int G, int tiles) {
+            const int spt = (int)(pf / tiles), ngroups = (int)((n - 11) / G);
+            run(name, [&] { hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * ngroups * (spt / 256))), dim3(256), 0, 0, (const uint2 *)a, (uint2 *)b, pf, (int)n, spt); });
+        };
+        w("W 8B G=4 tiles=1", kW<uint2, 4>, pf8, 4, 1);
+        w("W 8B G=4 tiles=4", kW<uint2, 4>, pf8, 4, 4);
+        w("W 8B G=4 tiles=8", kW<uint2, 4>, pf8, 4, 8);
+        w("W 8B G=4 tiles=16", kW<uint2, 4>, pf8, 4, 16);
+        w("W 8B G=8 tiles=4", kW<uint2, 8>, pf8, 8, 4);
+        w("W 8B G=8 tiles=8", kW<uint2, 8>, pf8, 8, 8);
+        w("W 8B G=8 tiles=16", kW<uint2, 8>, pf8, 8, 16);
+        w("W 8B G=2 tiles=8", kW<uint2, 2>, pf8, 2, 8);
+    }
     unsigned *cnt; CK(hipMalloc(&cnt, 4096));
-    run("K lockstep every 4 frames", [&] { hipMemsetAsync(cnt, 0, 4096, 0); hipLaunchKernelGGL((kK<4>), dim3(1600), dim3(256), 0, 0, (const uint4 *)a, (uint4 *)b, pf16, (int)n, cnt, 1600u); });
-    run("K lockstep every 8 frames", [&] { hipMemsetAsync(cnt, 0, 4096, 0); hipLaunchKernelGGL((kK<8>), dim3(1600), dim3(256), 0, 0, (const uint4 *)a, (uint4 *)b, pf16, (int)n, cnt, 1600u); });
-    run("K lockstep every 2 frames", [&] { hipMemsetAsync(cnt, 0, 4096, 0); hipLaunchKernelGGL((kK<2>), dim3(1600), dim3(256), 0, 0, (const uint4 *)a, (uint4 *)b, pf16, (int)n, cnt, 1600u); });
     CK(hipDeviceSynchronize());
     hipFree(a); hipFree(b);
     return 0;
