@@ -69,6 +69,7 @@ struct pseg_ctx {
     bool have_bits = false;       // threshold plane + masked sums already produced by the bg kernel
     DevBuf bounds, band_off, band_obj, trash, rp_small, rp_scratch;
     int bounds_n = -1, bounds_emit = -1, bounds_chunks = -1;
+    bool runs_old = false;        // wave-per-row run extraction (k_runs) instead of k_runs_quad (PSEG_RUNS_OLD)
     int bg_chunks = 1;            // time chunks of the streaming background kernel (PSEG_BG_CHUNKS)
     bool force_generic = false;   // PSEG_BG_GENERIC=1: use the 12x-read reference kernel (debug / cross-check)
     bool no_bands = false;        // PSEG_NO_BANDS=1: label with the global union-find only (the path of very dense frames)
@@ -633,6 +634,75 @@ __global__ __launch_bounds__(256) void k_runs(SegState S, int nrows)
             carry = __builtin_amdgcn_readlane(top, 63);
         }
         if (!FILL && lane == 0) S.rowcnt[row] = total;
+    }
+}
+// The same extraction with four lanes per row (wave = 16 rows): a lane walks its quarter of the row's words in order,
+// so the carry between words stays in the lane and a row costs a handful of instructions per word instead of a wave-wide
+// scan per row.  Starts are rare (about one word in fifty holds one), the walk over the words is the whole cost.
+template <bool FILL, int WPL>
+__global__ __launch_bounds__(256) void k_runs_quad(SegState S, int nrows, int wpl)
+{
+    const int lane = threadIdx.x & 63, part = lane & 3;
+    const int row = (blockIdx.x * 4 + (int)(threadIdx.x >> 6)) * RUNS_RPW + (lane >> 2);
+    bool want = row < nrows;
+    int f = 0, y = 0;
+    if (want) {
+        f = row / S.H; y = row - f * S.H;
+        if (!S.valid[f]) want = false;
+        else if (FILL && seg_rowcount(S, f, y) == 0) want = false;
+    }
+    const uint64_t *rb = S.bits + (size_t)(want ? row : 0) * S.WW;
+    const int w0 = part * wpl, nw = want ? (w0 + wpl < S.WW ? wpl : S.WW - w0) : 0;     // nw <= wpl <= WPL (may be <= 0)
+    // all words of the lane are requested at once: one memory latency per wave
+    uint64_t v[WPL];
+#pragma unroll
+    for (int k = 0; k < WPL; k++) v[k] = k < nw ? rb[w0 + k] : 0;
+    const uint64_t before = (w0 > 0 && nw > 0) ? rb[w0 - 1] : 0;
+    uint32_t cnt = 0;
+    {
+        uint64_t prev = before;
+#pragma unroll
+        for (int k = 0; k < WPL; k++) {
+            cnt += (uint32_t)__popcll(v[k] & ~((v[k] << 1) | (prev >> 63)));
+            prev = v[k];
+        }
+    }
+    // counts of the row's four lanes (quad broadcasts)
+    const uint32_t c0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cnt, 0x00, 0xf, 0xf, false);
+    const uint32_t c1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cnt, 0x55, 0xf, 0xf, false);
+    const uint32_t c2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cnt, 0xAA, 0xf, 0xf, false);
+    if (!FILL) {
+        const uint32_t c3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cnt, 0xFF, 0xf, 0xf, false);
+        if (part == 0 && row < nrows) S.rowcnt[row] = c0 + c1 + c2 + c3;
+        return;
+    }
+    if (cnt == 0) return;
+    int idx = seg_rowstart(S, f, y) + (int)((part > 0 ? c0 : 0u) + (part > 1 ? c1 : 0u) + (part > 2 ? c2 : 0u));
+    const uint32_t fy = (uint32_t)y | ((uint32_t)f << 16);
+    uint64_t prev = before;
+#pragma unroll
+    for (int k = 0; k < WPL; k++) {
+        const uint64_t vv = v[k];
+        uint64_t st = vv & ~((vv << 1) | (prev >> 63));
+        prev = vv;
+        const int w = w0 + k;
+        while (st) {
+            const int s = __ffsll((unsigned long long)st) - 1;
+            st &= st - 1;
+            const uint64_t t = ~(vv >> s);                   // zeros mark the run's extent from bit s
+            const int ones = t ? __ffsll((unsigned long long)t) - 1 : 64;
+            int xe = 64 * w + s + ones - 1;
+            if (s + ones == 64)                              // the run goes on into the next words (possibly another lane's)
+                for (int q = w + 1; q < S.WW; q++) {
+                    const uint64_t u = rb[q];
+                    if (u == ~0ull) { xe += 64; continue; }
+                    xe += __ffsll((unsigned long long)~u) - 1;
+                    break;
+                }
+            S.run_x[idx] = (uint32_t)(64 * w + s) | ((uint32_t)xe << 16);
+            S.run_fy[idx] = fy;
+            idx++;
+        }
     }
 }
 __global__ void k_init(SegState S, int nfg, int nt) { size_t g = GTID; if (g < (size_t)nt) init_body(S, (int)g, nfg); }
@@ -1419,6 +1489,7 @@ extern "C" int pseg_create(int device, int H, int W, int max_frames, pseg_ctx **
     ctx->own_stream = true;
     if (const char *e = getenv("PSEG_BG_CHUNKS")) ctx->bg_chunks = atoi(e) > 0 ? atoi(e) : 1;
     if (const char *e = getenv("PSEG_BG_GENERIC")) ctx->force_generic = atoi(e) != 0;
+    if (const char *e = getenv("PSEG_RUNS_OLD")) ctx->runs_old = atoi(e) != 0;
     if (const char *e = getenv("PSEG_NO_BANDS")) ctx->no_bands = atoi(e) != 0;
     for (auto &e : ctx->ev) if (hipEventCreate(&e) != hipSuccess) { delete ctx; return PSEG_ERR_HIP; }
     *out = ctx;
@@ -1654,7 +1725,11 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
     // (the counters were cleared by k_reduce_partials; the mask pixels were counted by the background kernel when it ran fused)
     if (mask && !ctx->mask_counted)
         hipLaunchKernelGGL(k_mask_count, dim3(1024), dim3(256), 0, st, mask, P, (unsigned long long *)ctx->maskcnt.p);
-    hipLaunchKernelGGL(k_runs<false>, dim3(nblocks((size_t)n * H, 4 * RUNS_RPW)), dim3(256), 0, st, S, n * H);
+    const int runs_wpl = (S.WW + 3) / 4;                     // words per lane of k_runs_quad
+    const dim3 runs_grid(nblocks((size_t)n * H, 4 * RUNS_RPW));
+    if (ctx->runs_old || runs_wpl > 16) hipLaunchKernelGGL(k_runs<false>, runs_grid, dim3(256), 0, st, S, n * H);       // rows wider than 4096 px
+    else if (runs_wpl > 10) hipLaunchKernelGGL((k_runs_quad<false, 16>), runs_grid, dim3(256), 0, st, S, n * H, runs_wpl);
+    else hipLaunchKernelGGL((k_runs_quad<false, 10>), runs_grid, dim3(256), 0, st, S, n * H, runs_wpl);
     hipLaunchKernelGGL(k_scan_rows, dim3(n), dim3(256), 0, st, S, ftot, S.framebase + n + 1);
     hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(256), 0, st, (const uint32_t *)ftot, S.framebase, n, 1, 1);
     HIPCHK(hipGetLastError());
@@ -1677,7 +1752,9 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
     S.extrank = (int32_t *)ctx->extrank.p; S.keptrank = (int32_t *)ctx->keptrank.p; S.savedrank = (int32_t *)ctx->savedrank.p;
     int32_t *objlabel = (int32_t *)ctx->objlabel.p, *objflag = (int32_t *)ctx->objflag.p;
 
-    if (nfg > 0) hipLaunchKernelGGL(k_runs<true>, dim3(nblocks((size_t)n * H, 4 * RUNS_RPW)), dim3(256), 0, st, S, n * H);
+    if (nfg > 0 && (ctx->runs_old || runs_wpl > 16)) hipLaunchKernelGGL(k_runs<true>, runs_grid, dim3(256), 0, st, S, n * H);
+    else if (nfg > 0 && runs_wpl > 10) hipLaunchKernelGGL((k_runs_quad<true, 16>), runs_grid, dim3(256), 0, st, S, n * H, runs_wpl);
+    else if (nfg > 0) hipLaunchKernelGGL((k_runs_quad<true, 10>), runs_grid, dim3(256), 0, st, S, n * H, runs_wpl);
     if (bandmax <= BAND_CAP && !ctx->no_bands) {
         // bands of BAND_H rows are labelled in LDS; the global kernels only unite across the band boundaries
         hipLaunchKernelGGL(k_band_label, dim3((H + BAND_H - 1) / BAND_H, n), dim3(256), 0, st, S);
