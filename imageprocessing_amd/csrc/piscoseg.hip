@@ -1019,7 +1019,12 @@ __global__ __launch_bounds__(256) void k_label_fill(SegState S, const int32_t *_
 
 // geometry of saved object s: geo[s*8] = f, x, y, w, h, root, words-per-row, row ; sz[s*3] = crop bytes,
 // mask words, row bands (a band = a run of rows of about CROP_BAND pixels: the unit of work of k_crops_sums)
+#ifndef CROP_BAND
 #define CROP_BAND 16384
+#endif
+#ifndef CROP_THREADS
+#define CROP_THREADS 256
+#endif
 #define CROP_LDS_WORDS 1536          // mask words of a band + 2 halo rows on each side (frames up to 8192 px wide)
 __host__ __device__ inline int crop_rows_per_band(int w)
 {
@@ -1098,7 +1103,7 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 // sums[s*PSEG_NSUMS + k]: 0 N, 1 sum r, 2 sum c, 3 sum r^2, 4 sum c^2, 5 sum r*c, 6 min I, 7 max I, 8 sum I,
 //   9 filled area, 10..12 perimeter code counts (weight 1, sqrt2, (1+sqrt2)/2), 13 euler, 14 convex area
 template <bool DENSE>
-__global__ __launch_bounds__(256) void k_crops_sums(SegState S, int n_saved, const int32_t *__restrict__ geo,
+__global__ __launch_bounds__(CROP_THREADS) void k_crops_sums(SegState S, int n_saved, const int32_t *__restrict__ geo,
                                                     const long long *__restrict__ crop_off, const long long *__restrict__ band_off,
                                                     const int32_t *__restrict__ objflag, const uint8_t *__restrict__ cleaned,
                                                     const uint8_t *__restrict__ raw, uint8_t *__restrict__ c_raw,
@@ -1116,12 +1121,12 @@ __global__ __launch_bounds__(256) void k_crops_sums(SegState S, int n_saved, con
     const int rpb = crop_rows_per_band(w);
     const int r0 = (int)(bid - band_off[s]) * rpb, r1 = (r0 + rpb < h) ? r0 + rpb : h;
     const int nrows = r1 - r0;
-    for (int wi = threadIdx.x; wi < (nrows + 4) * wpr; wi += 256) mbuf[wi] = 0;
+    for (int wi = threadIdx.x; wi < (nrows + 4) * wpr; wi += CROP_THREADS) mbuf[wi] = 0;
     if (threadIdx.x < 32) acc[threadIdx.x] = threadIdx.x == 15 ? 255u : 0u;    // acc[15] = running minimum
     __syncthreads();
     if (DENSE) {
         // pseg_regionprops: the mask is a dense uint8 image (nonzero = set) of row stride S.W instead of the run tables
-        for (int wi = threadIdx.x; wi < (nrows + 4) * wpr; wi += 256) {
+        for (int wi = threadIdx.x; wi < (nrows + 4) * wpr; wi += CROP_THREADS) {
             const int yl = wi / wpr, wx = wi - yl * wpr, yy = r0 - 2 + yl;
             uint32_t v = 0;
             if (yy >= 0 && yy < h) {
@@ -1143,7 +1148,7 @@ __global__ __launch_bounds__(256) void k_crops_sums(SegState S, int n_saved, con
                 atomicOr(&mrow[wd], m);
             }
         };
-        for (int yl = threadIdx.x >> 4; yl < nrows + 4; yl += 16) {
+        for (int yl = threadIdx.x >> 4; yl < nrows + 4; yl += CROP_THREADS / 16) {
             const int yy = r0 - 2 + yl;
             if (yy < 0 || yy >= h) continue;
             const int rs = seg_rowstart(S, f, by + yy), n = seg_rowcount(S, f, by + yy);
@@ -1162,7 +1167,7 @@ __global__ __launch_bounds__(256) void k_crops_sums(SegState S, int n_saved, con
     __syncthreads();
     // border = mask minus its erosion by the 4-neighbour cross, zero outside the window
     // (skimage perimeter(image, 4): binary_erosion(..., border_value=0), _regionprops_utils.py:225-231)
-    for (int wi = threadIdx.x; wi < (nrows + 2) * wpr; wi += 256) {
+    for (int wi = threadIdx.x; wi < (nrows + 2) * wpr; wi += CROP_THREADS) {
         int yl = wi / wpr, wx = wi - yl * wpr;             // row r0-1+yl  ->  mbuf row yl+1
         const uint32_t *m = mbuf + (yl + 1) * wpr;
         uint32_t c = m[wx], up = m[wx - wpr], dn = m[wx + wpr];
@@ -1187,7 +1192,7 @@ __global__ __launch_bounds__(256) void k_crops_sums(SegState S, int n_saved, con
         const int cpr = (w + 3) >> 2, nitem = nrows * cpr;
         const float rcp = 1.0f / (float)cpr;
 #pragma unroll 4
-        for (int p = threadIdx.x; p < nitem; p += 256) {
+        for (int p = threadIdx.x; p < nitem; p += CROP_THREADS) {
             int yl = (int)((float)p * rcp);               // p / cpr, corrected below (p < 2^24)
             int c = p - yl * cpr;
             if (c < 0) { yl--; c += cpr; } else if (c >= cpr) { yl++; c -= cpr; }
@@ -1212,7 +1217,7 @@ __global__ __launch_bounds__(256) void k_crops_sums(SegState S, int n_saved, con
             mn_e = pkmin(mn_e, __builtin_amdgcn_perm(0, out4, 0x0c020c00)); mn_o = pkmin(mn_o, __builtin_amdgcn_perm(0, out4, 0x0c030c01));
         }
     } else {                                              // windows narrower than a dword: thread per pixel
-        for (int p = threadIdx.x; p < nrows * w; p += 256) {
+        for (int p = threadIdx.x; p < nrows * w; p += CROP_THREADS) {
             const int yl = p / w, xx = p - yl * w;
             const uint32_t bit = (mb[yl * wpr] >> xx) & 1u;
             const uint32_t cv = sb[(size_t)yl * S.W + xx];
@@ -1236,7 +1241,7 @@ __global__ __launch_bounds__(256) void k_crops_sums(SegState S, int n_saved, con
     //           [[10,2,10],[2,1,2],[10,2,10]] over the border image is 1 + 2*n4 + 10*nd; n4 / nd are counted with bit-sliced adders
     uint32_t mo[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // n, wx n, wx^2 n, sk, wx sk, sk2, yl n, yl^2 n, yl wx n, yl sk
     uint32_t pc1 = 0, pc2 = 0, pc3 = 0;
-    for (int wi = threadIdx.x; wi < nrows * wpr; wi += 256) {
+    for (int wi = threadIdx.x; wi < nrows * wpr; wi += CROP_THREADS) {
         const uint32_t yl = (uint32_t)(wi / wpr), wx = (uint32_t)wi - yl * (uint32_t)wpr;
         const uint32_t v = mb[wi];
         if (v) {
@@ -1281,7 +1286,7 @@ __global__ __launch_bounds__(256) void k_crops_sums(SegState S, int n_saved, con
     int eul = 0;
     {
         const int ylast = (r1 == h) ? nrows + 1 : nrows;   // the last band also owns the quads below the window
-        for (int wi = threadIdx.x; wi < ylast * (wpr + 1); wi += 256) {
+        for (int wi = threadIdx.x; wi < ylast * (wpr + 1); wi += CROP_THREADS) {
             int yl = wi / (wpr + 1), wx = wi - yl * (wpr + 1);
             const uint32_t *B = mbuf + (yl + 2) * wpr, *T = B - wpr;     // bottom row r0+yl, top row r0+yl-1
             uint32_t tr = wx < wpr ? T[wx] : 0u, br = wx < wpr ? B[wx] : 0u;
@@ -1290,7 +1295,7 @@ __global__ __launch_bounds__(256) void k_crops_sums(SegState S, int n_saved, con
         }
     }
     // first / last set column of every row of the band (input of the convex hull kernel)
-    for (int yl = threadIdx.x; yl < nrows; yl += 256) {
+    for (int yl = threadIdx.x; yl < nrows; yl += CROP_THREADS) {
         const uint32_t *m = mb + yl * wpr;
         int first = 0x7fffffff, last = -1;
         for (int wx = 0; wx < wpr; wx++) if (m[wx]) { first = 32 * wx + __ffs(m[wx]) - 1; break; }
@@ -1834,7 +1839,7 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
         ENSURE(ctx->band_obj, (size_t)h_tot[2] * 4);
         hipLaunchKernelGGL(k_band_map, dim3(nblocks((size_t)n_saved, 4)), dim3(256), 0, st, n_saved, (const long long *)ctx->band_off.p,
                            (int32_t *)ctx->band_obj.p, d_sums);
-        hipLaunchKernelGGL(k_crops_sums<false>, dim3((unsigned)h_tot[2]), dim3(256), 0, st, S, n_saved, (const int32_t *)geo,
+        hipLaunchKernelGGL(k_crops_sums<false>, dim3((unsigned)h_tot[2]), dim3(CROP_THREADS), 0, st, S, n_saved, (const int32_t *)geo,
                            (const long long *)ctx->crop_off.p, (const long long *)ctx->band_off.p, (const int32_t *)objflag,
                            cleaned, raw, (uint8_t *)ctx->crops_raw.p, (uint8_t *)ctx->crops_masked.p,
                            (uint8_t *)ctx->crops_mask.p, d_sums, (const long long *)ctx->bits_off.p,
@@ -2127,7 +2132,7 @@ extern "C" int pseg_regionprops(pseg_ctx *ctx, const uint8_t *mask, const uint8_
     long long *d_sums = (long long *)(d + o_sums);
     uint8_t *c0 = (uint8_t *)ctx->rp_scratch.p;
     hipLaunchKernelGGL(k_init_sums, dim3(1), dim3(256), 0, st, d_sums, 1);
-    hipLaunchKernelGGL(k_crops_sums<true>, dim3(nbands), dim3(256), 0, st, S, 1, (const int32_t *)(d + o_geo), (const long long *)(d + o_ll),
+    hipLaunchKernelGGL(k_crops_sums<true>, dim3(nbands), dim3(CROP_THREADS), 0, st, S, 1, (const int32_t *)(d + o_geo), (const long long *)(d + o_ll),
                        (const long long *)(d + o_ll + 16), (const int32_t *)nullptr, img, img, c0, c0 + (size_t)w * h, c0 + (size_t)2 * w * h,
                        d_sums, (const long long *)(d + o_ll + 32), (int32_t *)(d + o_ext), (const int32_t *)(d + o_bobj), mask);
     if (lds > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void *)k_convex, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
