@@ -16,6 +16,7 @@
 #include <string.h>
 #include <string>
 #include <vector>
+#include <mutex>
 
 #include "../../include/piscoseg.h"
 #include "pseg_core.h"
@@ -70,6 +71,8 @@ struct pseg_ctx {
     DevBuf bounds, band_off, band_obj, trash, rp_small, rp_scratch;
     int bounds_n = -1, bounds_emit = -1, bounds_chunks = -1;
     bool runs_old = false;        // wave-per-row run extraction (k_runs) instead of k_runs_quad (PSEG_RUNS_OLD)
+    bool exclusive = true;        // the device part of a call holds the GPU's turn (PSEG_EXCLUSIVE=0: batches interleave freely)
+    struct GpuTurn *turn = nullptr;
     int bg_chunks = 1;            // time chunks of the streaming background kernel (PSEG_BG_CHUNKS)
     bool force_generic = false;   // PSEG_BG_GENERIC=1: use the 12x-read reference kernel (debug / cross-check)
     bool no_bands = false;        // PSEG_NO_BANDS=1: label with the global union-find only (the path of very dense frames)
@@ -1494,6 +1497,7 @@ extern "C" int pseg_create(int device, int H, int W, int max_frames, pseg_ctx **
     ctx->own_stream = true;
     if (const char *e = getenv("PSEG_BG_CHUNKS")) ctx->bg_chunks = atoi(e) > 0 ? atoi(e) : 1;
     if (const char *e = getenv("PSEG_BG_GENERIC")) ctx->force_generic = atoi(e) != 0;
+    if (const char *e = getenv("PSEG_EXCLUSIVE")) ctx->exclusive = atoi(e) != 0;
     if (const char *e = getenv("PSEG_RUNS_OLD")) ctx->runs_old = atoi(e) != 0;
     if (const char *e = getenv("PSEG_NO_BANDS")) ctx->no_bands = atoi(e) != 0;
     for (auto &e : ctx->ev) if (hipEventCreate(&e) != hipSuccess) { delete ctx; return PSEG_ERR_HIP; }
@@ -1546,6 +1550,32 @@ static int check_batch(pseg_ctx *ctx, int n)
 // frames share one window, bg_correction.py:72).  n_emit < n_avail: the leading part of a batch cut for another GPU;
 // the rest is the forward halo (>= window - 1 frames), so no emitted frame reaches the clamp -- the kernels are simply
 // told the batch is one frame longer than what they may read.
+// ---- one batch on the GPU at a time ---------------------------------------------------------------------------------
+// Several contexts (host threads) share a GPU so that the host part of one batch (table formatting, 0.4 ms) hides under the
+// kernels of another.  Letting the kernels of two batches interleave as well is a loss on this path: the streaming kernels
+// need every wave slot and the whole memory system (two label fills side by side take 2.9 ms instead of 2 x 0.8 ms; a fill
+// next to the other batch's labelling kernels 1.4 ms, measured with rocprofv3 kernel traces, profiles/README.md).  The
+// device part of a call therefore runs under a per-device turn; it is handed on after the call's last device
+// synchronisation, before its host work.
+#define PSEG_MAX_DEVICES 64
+static std::mutex g_turn_mu[PSEG_MAX_DEVICES];
+struct GpuTurn {
+    pseg_ctx *ctx; bool held = false;
+    explicit GpuTurn(pseg_ctx *c) : ctx(c)
+    {
+        if (!c || !c->exclusive || c->turn || c->device < 0 || c->device >= PSEG_MAX_DEVICES) return;
+        g_turn_mu[c->device].lock();
+        held = true; c->turn = this;
+    }
+    void release()
+    {
+        if (!held) return;
+        held = false; ctx->turn = nullptr;
+        g_turn_mu[ctx->device].unlock();
+    }
+    ~GpuTurn() { release(); }
+};
+
 static int run_bg(pseg_ctx *ctx, const uint8_t *frames, int n_avail, int n_emit, int n_bg_imgs, const uint8_t *mask, int thr,
                   uint8_t *cleaned)
 {
@@ -1639,6 +1669,7 @@ extern "C" int pseg_bgcorrect(pseg_ctx *ctx, const uint8_t *frames, int n, int n
     if (!frames || !cleaned) return fail(ctx, PSEG_ERR_ARG, "null frame pointer");
     ctx->have_bits = false;
     ctx->head_on_host = false;
+    GpuTurn turn(ctx);
     r = run_bg(ctx, frames, n, n, n_bg_imgs, nullptr, 255, cleaned);
     if (r) return r;
     r = fetch_raw_stats(ctx, n, mean_std, valid);
@@ -1876,6 +1907,7 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
         HIPCHK(hipMemcpyAsync(hp, ctx->outpack.p, o_bytes, hipMemcpyDeviceToHost, st));
     }
     HIPCHK(hipStreamSynchronize(st));
+    if (ctx->turn) ctx->turn->release();                    // the rest is host work: the next batch may have the GPU
     HIPCHK(hipEventElapsedTime(&ctx->ms[2], ctx->ev[2], ctx->ev[3]));
     HIPCHK(hipEventElapsedTime(&ctx->ms[3], ctx->ev[3], ctx->ev[4]));
     HIPCHK(hipEventElapsedTime(&ctx->ms[4], ctx->ev[4], ctx->ev[5]));
@@ -1931,6 +1963,7 @@ extern "C" int pseg_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t 
     ENSURE(ctx->bits, (size_t)n * P / 8);
     ENSURE(ctx->partials, (size_t)n * nblk * 4 * sizeof(uint32_t));
     { int r_ = head_setup(ctx, n); if (r_) return r_; }
+    GpuTurn turn(ctx);
     HIPCHK(hipEventRecord(ctx->ev[6], ctx->stream));
     if (valid) HIPCHK(hipMemcpyAsync(ctx->valid_dev.p, valid, n, hipMemcpyHostToDevice, ctx->stream));
     else HIPCHK(hipMemsetAsync(ctx->valid_dev.p, 1, n, ctx->stream));
@@ -1963,6 +1996,7 @@ extern "C" int pseg_process_part(pseg_ctx *ctx, const uint8_t *frames, int n_ava
     if (!frames || !cleaned) return fail(ctx, PSEG_ERR_ARG, "null frame pointer");
     if (n_emit < 1 || n_emit > n_avail) return fail(ctx, PSEG_ERR_ARG, "n_emit out of range");
     const int n = n_emit;
+    GpuTurn turn(ctx);
     HIPCHK(hipEventRecord(ctx->ev[6], ctx->stream));
     r = run_bg(ctx, frames, n_avail, n_emit, n_bg_imgs, mask, threshold, cleaned);
     if (r) return r;
