@@ -1559,6 +1559,10 @@ static int check_batch(pseg_ctx *ctx, int n)
 // synchronisation, before its host work.
 #define PSEG_MAX_DEVICES 64
 static std::mutex g_turn_mu[PSEG_MAX_DEVICES];
+static hipEvent_t g_turn_ev[PSEG_MAX_DEVICES];              // recorded behind the last kernel of the previous holder
+static bool g_turn_ev_set[PSEG_MAX_DEVICES];
+// The hand-over happens on the device: the holder records the event behind its last kernel and lets go while that kernel
+// is still queued; the next holder makes its stream wait for the event and can queue its first kernels at once.
 struct GpuTurn {
     pseg_ctx *ctx; bool held = false;
     explicit GpuTurn(pseg_ctx *c) : ctx(c)
@@ -1566,12 +1570,17 @@ struct GpuTurn {
         if (!c || !c->exclusive || c->turn || c->device < 0 || c->device >= PSEG_MAX_DEVICES) return;
         g_turn_mu[c->device].lock();
         held = true; c->turn = this;
+        if (g_turn_ev_set[c->device]) (void)hipStreamWaitEvent(c->stream, g_turn_ev[c->device], 0);
     }
-    void release()
+    void release()                                           // call after the last kernel of the device part is queued
     {
         if (!held) return;
+        const int d = ctx->device;
+        if (!g_turn_ev_set[d]) g_turn_ev_set[d] = hipEventCreateWithFlags(&g_turn_ev[d], hipEventDisableTiming) == hipSuccess;
+        if (g_turn_ev_set[d]) (void)hipEventRecord(g_turn_ev[d], ctx->stream);
+        else (void)hipStreamSynchronize(ctx->stream);        // no event: hand over on the host
         held = false; ctx->turn = nullptr;
-        g_turn_mu[ctx->device].unlock();
+        g_turn_mu[d].unlock();
     }
     ~GpuTurn() { release(); }
 };
@@ -1904,10 +1913,10 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
                            (int32_t *)((char *)ctx->outpack.p + o_rows), (int32_t *)((char *)ctx->outpack.p + o_srow),
                            (long long *)((char *)ctx->outpack.p + o_coff));
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(hp, ctx->outpack.p, o_bytes, hipMemcpyDeviceToHost, st));
     }
+    if (ctx->turn) ctx->turn->release();                    // last kernel queued: the next batch may follow it on the GPU
+    if (n_rows > 0) HIPCHK(hipMemcpyAsync(hp, ctx->outpack.p, o_bytes, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    if (ctx->turn) ctx->turn->release();                    // the rest is host work: the next batch may have the GPU
     HIPCHK(hipEventElapsedTime(&ctx->ms[2], ctx->ev[2], ctx->ev[3]));
     HIPCHK(hipEventElapsedTime(&ctx->ms[3], ctx->ev[3], ctx->ev[4]));
     HIPCHK(hipEventElapsedTime(&ctx->ms[4], ctx->ev[4], ctx->ev[5]));
