@@ -50,7 +50,7 @@ def main():
                     "(reference topology: bg_correction.py:120 / segmenter.py:252); '1,1' = single core, in-process")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo + --single-device rehearses the N > 1 path on one GPU")
     ap.add_argument("--single-device", action="store_true", help="every rank uses cuda:0 (rehearsal only; never a measurement)")
-    ap.add_argument("--streams", type=int, default=2, help="contexts (own HIP stream + host thread each) that alternate batches")
+    ap.add_argument("--streams", type=int, default=3, help="contexts (own HIP stream + host thread each) that alternate batches")
     args = ap.parse_args()
 
     import torch

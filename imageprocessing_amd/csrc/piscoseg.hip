@@ -72,6 +72,7 @@ struct pseg_ctx {
     int bounds_n = -1, bounds_emit = -1, bounds_chunks = -1;
     bool runs_old = false;        // wave-per-row run extraction (k_runs) instead of k_runs_quad (PSEG_RUNS_OLD)
     bool exclusive = true;        // the device part of a call holds the GPU's turn (PSEG_EXCLUSIVE=0: batches interleave freely)
+    bool early_release = true;    // hand the turn on behind the label fill instead of behind the last kernel (PSEG_EARLY_RELEASE=0)
     struct GpuTurn *turn = nullptr;
     int bg_chunks = 1;            // time chunks of the streaming background kernel (PSEG_BG_CHUNKS)
     bool force_generic = false;   // PSEG_BG_GENERIC=1: use the 12x-read reference kernel (debug / cross-check)
@@ -1498,6 +1499,7 @@ extern "C" int pseg_create(int device, int H, int W, int max_frames, pseg_ctx **
     if (const char *e = getenv("PSEG_BG_CHUNKS")) ctx->bg_chunks = atoi(e) > 0 ? atoi(e) : 1;
     if (const char *e = getenv("PSEG_BG_GENERIC")) ctx->force_generic = atoi(e) != 0;
     if (const char *e = getenv("PSEG_EXCLUSIVE")) ctx->exclusive = atoi(e) != 0;
+    if (const char *e = getenv("PSEG_EARLY_RELEASE")) ctx->early_release = atoi(e) != 0;
     if (const char *e = getenv("PSEG_RUNS_OLD")) ctx->runs_old = atoi(e) != 0;
     if (const char *e = getenv("PSEG_NO_BANDS")) ctx->no_bands = atoi(e) != 0;
     for (auto &e : ctx->ev) if (hipEventCreate(&e) != hipSuccess) { delete ctx; return PSEG_ERR_HIP; }
@@ -1858,6 +1860,9 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(ctx->ev[4], st));
+    // The streaming kernels of this batch are queued.  What follows (crops, properties, hulls) waits on memory latency and
+    // fills neither the vector units nor the memory system: the next batch's background kernel may run beside it.
+    if (ctx->turn && ctx->early_release) ctx->turn->release();
     HIPCHK(hipEventSynchronize(ctx->ev[3]));
     ctx->head_on_host = true;
     const HeadHost hh = head_host(ctx, n);

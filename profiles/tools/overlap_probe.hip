@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
+#include <cstdlib>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void k_fill(int *out, int W, int H)
@@ -34,7 +35,11 @@ int main()
         free(h);
     }
     hipStream_t a, b;
-    CK(hipStreamCreate(&a)); CK(hipStreamCreate(&b));
+    int plo = 0, phi = 0;
+    CK(hipDeviceGetStreamPriorityRange(&plo, &phi));
+    printf("stream priorities: least %d greatest %d\n", plo, phi);
+    if (getenv("FILL_HIGH")) { CK(hipStreamCreateWithPriority(&a, hipStreamDefault, phi)); CK(hipStreamCreateWithPriority(&b, hipStreamDefault, plo)); printf("fill on the high-priority stream\n"); }
+    else { CK(hipStreamCreate(&a)); CK(hipStreamCreate(&b)); }
     hipEvent_t e0, e1, dep;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreateWithFlags(&dep, hipEventDisableTiming));
     const dim3 grid((W + 1023) / 1024, H, F);
