@@ -1893,8 +1893,10 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
                            (uint8_t *)ctx->crops_mask.p, d_sums, (const long long *)ctx->bits_off.p,
                            (int32_t *)ctx->maskbits.p, (const int32_t *)ctx->band_obj.p, (const uint8_t *)nullptr);
         const int hmax = (int)h_tot[3];
-        // two size classes: objects up to 256 rows keep 10 KB of LDS per block, the rest is sized by the tallest one
-        const int hsmall = hmax < 256 ? hmax : 256;
+        // two size classes when tall objects are present: objects up to 256 rows keep 14 KB of LDS per block, the rest is sized by
+        // the tallest one
+        // (a tallest object of up to 448 rows = 25 KB still leaves 6 blocks per CU: one launch, one kernel latency less)
+        const int hsmall = hmax <= 448 ? hmax : 256;
         const size_t lds_small = (size_t)hsmall * HULL_LDS_PER_ROW + 64, lds_big = (size_t)hmax * HULL_LDS_PER_ROW + 64;
         if (lds_big > 150 * 1024) return fail(ctx, PSEG_ERR_CAPACITY, "saved object too tall for the convex-hull kernel (limit 2700 rows)");
         if (lds_big > 48 * 1024)
