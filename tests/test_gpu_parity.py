@@ -296,3 +296,65 @@ def test_threshold_extremes_and_all_foreground(gpu_seg_factory):
     tab = seg.detect(torch.from_numpy(cl).cuda(), labels=labels, fetch_crops=True)
     helpers.compare_table(tab, dets, H, W, labels=labels.cpu().numpy())
     assert (tab.w[0], tab.h[0]) == (W, H) and tab.area[0] == (W - 1) * (H - 1)
+
+
+def test_contexts_taking_turns_give_the_single_context_results():
+    """Three contexts on three host threads share the GPU through the library's per-device turn (hand-over on the device
+    behind the label fill, the next batch's background kernel beside this batch's crop kernels): every batch must come
+    out exactly as it does from one context working alone, and against the oracle for one of them."""
+    import threading
+    import torch
+    from imageprocessing_amd.engine import Segmenter
+    H, W, n, nctx, rounds = 256, 384, 16, 3, 4
+    mask = helpers.make_disk(H, W, 120)
+    dmask = torch.from_numpy(mask).cuda()
+    stacks = [_stack(n, H, W, 40 + k, per_frame=14, dmin=25, dmax=500)[0] for k in range(nctx * rounds)]
+    dev = [torch.from_numpy(s).cuda() for s in stacks]
+
+    def snapshot(tab, cleaned, labels):
+        return dict(rows=np.stack([tab.frame, tab.c, tab.label, tab.x, tab.y, tab.w, tab.h, tab.saved.astype(np.int32)]).copy(),
+                    area=tab.area.copy(), props=tab.saved_props.copy(), sums=tab.sums.copy(),
+                    crops={k: v.copy() for k, v in tab.crops.items()}, mean=tab.frame_mean.copy(),
+                    cleaned=cleaned.cpu().numpy(), labels=labels.cpu().numpy())
+
+    ref_seg = Segmenter(H, W, max_frames=n, device=0)
+    want = []
+    for d in dev:
+        labels = torch.empty((n, H, W), dtype=torch.int32, device="cuda")
+        cleaned, _, _, tab = ref_seg.process(d, mask=dmask, labels=labels, fetch_crops=True)
+        want.append(snapshot(tab, cleaned, labels))
+    dets = helpers.oracle_detect(helpers.oracle_bgcorrect(stacks[0]), mask)
+    labels = torch.empty((n, H, W), dtype=torch.int32, device="cuda")
+    _, _, _, tab = ref_seg.process(dev[0], mask=dmask, labels=labels, fetch_crops=True)
+    helpers.compare_table(tab, dets, H, W, labels=labels.cpu().numpy())
+    ref_seg.close()
+
+    segs = [Segmenter(H, W, max_frames=n, device=0) for _ in range(nctx)]
+    got, errors = {}, []
+
+    def worker(k):
+        try:
+            labels = torch.empty((n, H, W), dtype=torch.int32, device="cuda")
+            for r in range(rounds):
+                i = r * nctx + k
+                cleaned, _, _, tab = segs[k].process(dev[i], mask=dmask, labels=labels, fetch_crops=True)
+                got[i] = snapshot(tab, cleaned, labels)
+        except Exception as e:                               # surfaces in the main thread
+            errors.append(e)
+
+    ths = [threading.Thread(target=worker, args=(k,)) for k in range(nctx)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(120)
+        assert not t.is_alive(), "a context is stuck waiting for its turn"
+    assert not errors, errors
+    for s in segs:
+        s.close()
+    assert sum(w["rows"].shape[1] for w in want) > 100
+    for i, w in enumerate(want):
+        g = got[i]
+        for key in ("rows", "area", "props", "sums", "mean", "cleaned", "labels"):
+            assert np.array_equal(g[key], w[key], equal_nan=(key in ("props", "mean"))), (i, key)
+        for plane in w["crops"]:
+            assert np.array_equal(g["crops"][plane], w["crops"][plane]), (i, plane)
