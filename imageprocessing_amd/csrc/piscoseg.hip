@@ -309,7 +309,7 @@ __device__ __forceinline__ uint32_t pkadd(uint32_t a, uint32_t b) { return __bui
 struct BgEmit {
     uint8_t *cleaned, *bits8; uint4 *partials;              // real outputs
     uint8_t *t_cleaned, *t_bits8; uint4 *t_partials;        // trash rows: where a disabled step stores (keeps the loop branch-free)
-    size_t P; uint32_t off8, strip32; uint2 inm; uint32_t kadd, inm8; uint32_t nwaves, wave;
+    size_t P; uint32_t off8, strip32; uint2 inm; uint32_t kadd, lowm, inm8; uint32_t nwaves, wave;
     uint32_t act;          // 0xffffffff for strips inside the frame, 0 for the padding lanes of the last wave
 };
 __device__ __forceinline__ uint32_t gather4(uint32_t r)     // bits 7,15,23,31 -> bits 0..3
@@ -338,11 +338,12 @@ __device__ __forceinline__ void bg_emit(const BgEmit &E, uint2 img, Px8 c, Px8 b
     uint32_t s1 = __builtin_amdgcn_udot4(img.x, img.x, __builtin_amdgcn_udot4(img.y, img.y, 0u, false), false);
     uint32_t s2 = __builtin_amdgcn_sad_u8(cm.x, 0u, __builtin_amdgcn_sad_u8(cm.y, 0u, 0u));
     uint32_t s3 = __builtin_amdgcn_udot4(cm.x, cm.x, __builtin_amdgcn_udot4(cm.y, cm.y, 0u, false), false);
-    // threshold bits: d + (0x8000 - t) has bit 15 set iff d >= t (d < 256); the flag bytes of the four registers are
-    // gathered with two byte permutes, the mask is applied on the 8 result bits
-    uint32_t fe0 = pkadd(de0, E.kadd), fo0 = pkadd(do0, E.kadd), fe1 = pkadd(de1, E.kadd), fo1 = pkadd(do1, E.kadd);
-    uint32_t lo4 = __builtin_amdgcn_perm(fo0, fe0, 0x07030501) & 0x80808080u, hi4 = __builtin_amdgcn_perm(fo1, fe1, 0x07030501) & 0x80808080u;
-    uint32_t b = (gather4(lo4) | (gather4(hi4) << 4)) & E.inm8;
+    // threshold bits on the packed difference bytes: (d & 0x7f) + (128 - t) carries into bit 7 iff the low seven bits reach
+    // t (t <= 128; together with "d >= 128" by OR) resp. t - 128 (t > 128; AND) -- no carry crosses a byte.  The four flag
+    // bits of a register are gathered by one dot product with the weights 1, 2, 4, 8 (16 .. 128 for the upper register).
+    const uint32_t t0 = (corr.x & 0x7f7f7f7fu) + E.kadd, t1 = (corr.y & 0x7f7f7f7fu) + E.kadd;
+    const uint32_t f0 = ((t0 & corr.x) | ((t0 | corr.x) & E.lowm)) & 0x80808080u, f1 = ((t1 & corr.y) | ((t1 | corr.y) & E.lowm)) & 0x80808080u;
+    const uint32_t b = __builtin_amdgcn_udot4(f1 >> 7, 0x80402010u, __builtin_amdgcn_udot4(f0 >> 7, 0x08040201u, 0u, false), false) & E.inm8;
     pb[E.strip32] = (uint8_t)b;
     // wave sums, valid in lane 63: sum x and sum c (<= 2040 per lane) travel packed in one register until the last step
     uint32_t p = s0 | (s2 << 16);
@@ -405,7 +406,8 @@ __global__ __launch_bounds__(256, 4) void k_bg_stream(const uint8_t *__restrict_
     E.inm.x &= E.act; E.inm.y &= E.act;
     const int t1 = thr + 1 > 0 ? thr + 1 : 0;               // pixel > thr  <=>  pixel >= thr + 1 (negative thr: every pixel)
     const bool thr_ok = t1 <= 255;                          // thr >= 255: no pixel passes
-    E.kadd = thr_ok ? (uint32_t)(0x8000 - t1) * 0x00010001u : 0u;
+    E.kadd = (uint32_t)(t1 <= 128 ? 128 - t1 : 256 - (t1 > 255 ? 255 : t1)) * 0x01010101u;
+    E.lowm = t1 <= 128 ? 0xffffffffu : 0u;
     E.inm8 = thr_ok ? (gather4(E.inm.x & 0x80808080u) | (gather4(E.inm.y & 0x80808080u) << 4)) : 0u;
     E.nwaves = gridDim.x * 4; E.wave = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (mask && blockIdx.y == 0) {                          // pixels with mask == 255, per wave (summed by k_reduce_partials)
