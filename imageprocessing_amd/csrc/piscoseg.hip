@@ -300,6 +300,27 @@ __device__ __forceinline__ Px8 px_max(Px8 a, Px8 b) { return {pkmax(a.e0, b.e0),
 __device__ __forceinline__ Px8 px_min(Px8 a, Px8 b) { return {pkmin(a.e0, b.e0), pkmin(a.o0, b.o0), pkmin(a.e1, b.e1), pkmin(a.o1, b.o1)}; }
 
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+// A wave-uniform base pointer pinned to scalar registers: the 32-bit lane offset added to it becomes the instruction's
+// offset operand (global_load / global_store with an SGPR base) instead of 64-bit vector arithmetic per access.
+#define PSEG_GLOBAL __attribute__((address_space(1)))
+template <typename T>
+__device__ __forceinline__ T PSEG_GLOBAL *uniform_base(const void *p)
+{
+    const unsigned long long v = (unsigned long long)p;
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return (T PSEG_GLOBAL *)(((unsigned long long)hi << 32) | lo);
+}
+// raw buffer resource over a wave-uniform base: buffer_load / buffer_store take the 32-bit lane offset as it is ("offen"),
+// no vector arithmetic for the address; aux 2 = non-temporal
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t raw_rsrc(const void *base)
+{
+    return __builtin_amdgcn_make_buffer_rsrc((void *)uniform_base<uint8_t>(base), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ uint2 ld_stream_at(const uint8_t *base, uint32_t off)      // base wave-uniform
+{
+    const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(raw_rsrc(base), (int)off, 0, 2);
+    return make_uint2(v.x, v.y);
+}
 __device__ __forceinline__ uint2 ld_stream(const uint8_t *p)
 {
     u32x2_t v = __builtin_nontemporal_load((const u32x2_t *)p);
@@ -309,7 +330,7 @@ __device__ __forceinline__ uint32_t pkadd(uint32_t a, uint32_t b) { return __bui
 struct BgEmit {
     uint8_t *cleaned, *bits8; uint4 *partials;              // real outputs
     uint8_t *t_cleaned, *t_bits8; uint4 *t_partials;        // trash rows: where a disabled step stores (keeps the loop branch-free)
-    size_t P; uint32_t off8, strip32; uint2 inm; uint32_t kadd, lowm, inm8; uint32_t nwaves, wave;
+    size_t P; uint32_t off8, strip32; uint2 inm, m80; uint32_t kadd, lowm; uint32_t nwaves, wave;
     uint32_t act;          // 0xffffffff for strips inside the frame, 0 for the padding lanes of the last wave
 };
 __device__ __forceinline__ uint32_t gather4(uint32_t r)     // bits 7,15,23,31 -> bits 0..3
@@ -319,6 +340,7 @@ __device__ __forceinline__ uint32_t gather4(uint32_t r)     // bits 7,15,23,31 -
 }
 // frame s: cleaned = 255 - |img - bg| (bg_correction.py:80-81), the four sums and the threshold bits
 // (detection.py:178-202).  c = px_split(img).  en is wave-uniform; a disabled call stores into the trash rows.
+template <bool PAD>
 __device__ __forceinline__ void bg_emit(const BgEmit &E, uint2 img, Px8 c, Px8 bg, int s, bool en)
 {
     uint32_t de0 = pksub(pkmax(c.e0, bg.e0), pkmin(c.e0, bg.e0)), do0 = pksub(pkmax(c.o0, bg.o0), pkmin(c.o0, bg.o0));
@@ -326,14 +348,19 @@ __device__ __forceinline__ void bg_emit(const BgEmit &E, uint2 img, Px8 c, Px8 b
     uint2 corr = make_uint2(__builtin_amdgcn_perm(do0, de0, 0x06020400), __builtin_amdgcn_perm(do1, de1, 0x06020400));
     // every store is unconditional (disabled steps and padding lanes write to the trash rows): with no
     // branch in the loop body the compiler counts the outstanding loads exactly (vmcnt counts stores too)
-    const bool real = en && E.act;
+    const bool real = PAD ? (en && E.act) : en;           // without padding lanes the bases stay wave-uniform (scalar registers)
     uint8_t *pc = real ? E.cleaned + (size_t)s * E.P : E.t_cleaned;          // wave-uniform bases, 32-bit lane offsets
     uint8_t *pb = real ? E.bits8 + (size_t)s * (E.P / 8) : E.t_bits8;
     uint4 *pp = en ? E.partials + (size_t)s * E.nwaves : E.t_partials;
+
     // streamed out: a plain store would leave 1.3 GB of dirty lines to drain from L2 under the kernels that follow
-    { u32x2_t cv; cv.x = ~corr.x; cv.y = ~corr.y; __builtin_nontemporal_store(cv, (u32x2_t *)(pc + E.off8)); }
+    {
+        u32x2_t cv; cv.x = ~corr.x; cv.y = ~corr.y;
+        if (PAD) __builtin_nontemporal_store(cv, (u32x2_t *)(pc + E.off8));
+        else __builtin_amdgcn_raw_buffer_store_b64(cv, raw_rsrc(pc), (int)E.off8, 0, 2);
+    }
     uint2 cm = make_uint2(corr.x & E.inm.x, corr.y & E.inm.y);
-    img.x &= E.act; img.y &= E.act;
+    if (PAD) { img.x &= E.act; img.y &= E.act; }
     uint32_t s0 = __builtin_amdgcn_sad_u8(img.x, 0u, __builtin_amdgcn_sad_u8(img.y, 0u, 0u));
     uint32_t s1 = __builtin_amdgcn_udot4(img.x, img.x, __builtin_amdgcn_udot4(img.y, img.y, 0u, false), false);
     uint32_t s2 = __builtin_amdgcn_sad_u8(cm.x, 0u, __builtin_amdgcn_sad_u8(cm.y, 0u, 0u));
@@ -341,10 +368,13 @@ __device__ __forceinline__ void bg_emit(const BgEmit &E, uint2 img, Px8 c, Px8 b
     // threshold bits on the packed difference bytes: (d & 0x7f) + (128 - t) carries into bit 7 iff the low seven bits reach
     // t (t <= 128; together with "d >= 128" by OR) resp. t - 128 (t > 128; AND) -- no carry crosses a byte.  The four flag
     // bits of a register are gathered by one dot product with the weights 1, 2, 4, 8 (16 .. 128 for the upper register).
+    // OR / AND of the two conditions = majority with a constant third input (all ones: OR, zero: AND), one v_bitop3;
+    // m80 = bit 7 of the bytes inside the mask (0 when no pixel can pass): isolates the flags and applies the mask at once
     const uint32_t t0 = (corr.x & 0x7f7f7f7fu) + E.kadd, t1 = (corr.y & 0x7f7f7f7fu) + E.kadd;
-    const uint32_t f0 = ((t0 & corr.x) | ((t0 | corr.x) & E.lowm)) & 0x80808080u, f1 = ((t1 & corr.y) | ((t1 | corr.y) & E.lowm)) & 0x80808080u;
-    const uint32_t b = __builtin_amdgcn_udot4(f1 >> 7, 0x80402010u, __builtin_amdgcn_udot4(f0 >> 7, 0x08040201u, 0u, false), false) & E.inm8;
-    pb[E.strip32] = (uint8_t)b;
+    const uint32_t f0 = __builtin_amdgcn_bitop3_b32(t0, corr.x, E.lowm, 0xE8) & E.m80.x, f1 = __builtin_amdgcn_bitop3_b32(t1, corr.y, E.lowm, 0xE8) & E.m80.y;
+    const uint32_t b = __builtin_amdgcn_udot4(f1, 0x80402010u, __builtin_amdgcn_udot4(f0, 0x08040201u, 0u, false), false) >> 7;
+    if (PAD) pb[E.strip32] = (uint8_t)b;
+    else __builtin_amdgcn_raw_buffer_store_b8((uint8_t)b, raw_rsrc(pb), (int)E.strip32, 0, 0);
     // wave sums, valid in lane 63: sum x and sum c (<= 2040 per lane) travel packed in one register until the last step
     uint32_t p = s0 | (s2 << 16);
     p = dpp_add<0x111, 0xf>(p); p = dpp_add<0x112, 0xf>(p); p = dpp_add<0x114, 0xf>(p); p = dpp_add<0x118, 0xf>(p);
@@ -363,13 +393,13 @@ struct BgRegs {
     Px8 mp, t2[2], t4[4], t8[4], last;
 };
 #define BG_SLOTS 16
-template <int PH>
+template <int PH, bool PAD>
 __device__ __forceinline__ void bg_step(BgRegs &R, uint2 *ring, const BgEmit &E, const uint8_t *__restrict__ src, int k, int a,
                                         int kend, int n)
 {
     const uint2 cur = R.pf[PH];
     int kn = k + 4 <= kend ? k + 4 : kend;                  // clamped prefetch: always a valid frame
-    R.pf[PH] = ld_stream(src + (size_t)kn * E.P + E.off8);  // src is wave-uniform
+    R.pf[PH] = ld_stream_at(src + (size_t)kn * E.P, E.off8);   // src is wave-uniform
     ring[(k & (BG_SLOTS - 1)) * 256] = cur;
     const uint2 old = ring[((k - 11) & (BG_SLOTS - 1)) * 256];   // frame k-11 (zeros during warm-up)
     const Px8 cs = px_split(cur);
@@ -381,10 +411,12 @@ __device__ __forceinline__ void bg_step(BgRegs &R, uint2 *ring, const BgEmit &E,
     Px8 t8 = px_max(t4, R.t4[(PH + 3) & 3]); R.t4[(PH + 3) & 3] = t4;
     Px8 t11 = px_max(t8, R.t8[PH & 3]); R.t8[(PH + 3) & 3] = t8;
     R.last = t11;
-    bg_emit(E, old, px_split(old), t11, k - 11, k - 11 >= a && k < n - 1);
+    bg_emit<PAD>(E, old, px_split(old), t11, k - 11, k - 11 >= a && k < n - 1);
 }
 
-// grid = (ceil(P/2048), chunks); chunk c emits frames [bounds[c], bounds[c+1])
+// grid = (ceil(P/2048), chunks); chunk c emits frames [bounds[c], bounds[c+1]).  PAD: the last block has lanes beyond the frame
+// (P % 2048 != 0).
+template <bool PAD>
 __global__ __launch_bounds__(256, 4) void k_bg_stream(const uint8_t *__restrict__ frames, int n, size_t P, uint8_t *__restrict__ cleaned,
                                                       const uint8_t *__restrict__ mask, int thr, uint8_t *__restrict__ bits8,
                                                       uint4 *__restrict__ partials, const int *__restrict__ bounds,
@@ -408,7 +440,7 @@ __global__ __launch_bounds__(256, 4) void k_bg_stream(const uint8_t *__restrict_
     const bool thr_ok = t1 <= 255;                          // thr >= 255: no pixel passes
     E.kadd = (uint32_t)(t1 <= 128 ? 128 - t1 : 256 - (t1 > 255 ? 255 : t1)) * 0x01010101u;
     E.lowm = t1 <= 128 ? 0xffffffffu : 0u;
-    E.inm8 = thr_ok ? (gather4(E.inm.x & 0x80808080u) | (gather4(E.inm.y & 0x80808080u) << 4)) : 0u;
+    E.m80 = thr_ok ? make_uint2(E.inm.x & 0x80808080u, E.inm.y & 0x80808080u) : make_uint2(0u, 0u);
     E.nwaves = gridDim.x * 4; E.wave = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (mask && blockIdx.y == 0) {                          // pixels with mask == 255, per wave (summed by k_reduce_partials)
         const uint32_t mc = wave_sum63((uint32_t)__popc(gather4(E.inm.x & 0x80808080u) | (gather4(E.inm.y & 0x80808080u) << 4)));
@@ -427,19 +459,19 @@ __global__ __launch_bounds__(256, 4) void k_bg_stream(const uint8_t *__restrict_
     for (int i = 0; i < 4; i++) R.pf[i] = ld_stream(src + (size_t)(a + i <= kend ? a + i : kend) * P + E.off8);
     int k = a;
     for (; k + 3 <= kend; k += 4) {                         // branch-free body: counted waits keep 4 loads in flight
-        bg_step<0>(R, ring, E, src, k, a, kend, n);
-        bg_step<1>(R, ring, E, src, k + 1, a, kend, n);
-        bg_step<2>(R, ring, E, src, k + 2, a, kend, n);
-        bg_step<3>(R, ring, E, src, k + 3, a, kend, n);
+        bg_step<0, PAD>(R, ring, E, src, k, a, kend, n);
+        bg_step<1, PAD>(R, ring, E, src, k + 1, a, kend, n);
+        bg_step<2, PAD>(R, ring, E, src, k + 2, a, kend, n);
+        bg_step<3, PAD>(R, ring, E, src, k + 3, a, kend, n);
     }
-    if (k <= kend) bg_step<0>(R, ring, E, src, k, a, kend, n);
-    if (k + 1 <= kend) bg_step<1>(R, ring, E, src, k + 1, a, kend, n);
-    if (k + 2 <= kend) bg_step<2>(R, ring, E, src, k + 2, a, kend, n);
+    if (k <= kend) bg_step<0, PAD>(R, ring, E, src, k, a, kend, n);
+    if (k + 1 <= kend) bg_step<1, PAD>(R, ring, E, src, k + 1, a, kend, n);
+    if (k + 2 <= kend) bg_step<2, PAD>(R, ring, E, src, k + 2, a, kend, n);
     if (b == n) {                                           // the last 12 frames share bg[n-12] = T11 of the final step
 #pragma unroll 1
         for (int i = n - 12; i < n; i++) {
             const uint2 img = ld_stream(src + (size_t)i * P + E.off8);
-            bg_emit(E, img, px_split(img), R.last, i, true);
+            bg_emit<PAD>(E, img, px_split(img), R.last, i, true);
         }
     }
 }
@@ -1627,8 +1659,12 @@ static int run_bg(pseg_ctx *ctx, const uint8_t *frames, int n_avail, int n_emit,
         }
     }
     HIPCHK(hipEventRecord(ctx->ev[0], ctx->stream));
-    if (stream)
-        hipLaunchKernelGGL(k_bg_stream, dim3(nblk, chunks), dim3(256), 0, ctx->stream, frames, n_kernel, P, cleaned, mask, thr,
+    if (stream && P % 2048 == 0)
+        hipLaunchKernelGGL(k_bg_stream<false>, dim3(nblk, chunks), dim3(256), 0, ctx->stream, frames, n_kernel, P, cleaned, mask, thr,
+                           (uint8_t *)ctx->bits.p, (uint4 *)ctx->partials.p, (const int *)ctx->bounds.p, (uint8_t *)ctx->trash.p,
+                           (uint32_t *)ctx->maskpart.p);
+    else if (stream)
+        hipLaunchKernelGGL(k_bg_stream<true>, dim3(nblk, chunks), dim3(256), 0, ctx->stream, frames, n_kernel, P, cleaned, mask, thr,
                            (uint8_t *)ctx->bits.p, (uint4 *)ctx->partials.p, (const int *)ctx->bounds.p, (uint8_t *)ctx->trash.p,
                            (uint32_t *)ctx->maskpart.p);
     else
