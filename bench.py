@@ -51,6 +51,8 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo + --single-device rehearses the N > 1 path on one GPU")
     ap.add_argument("--single-device", action="store_true", help="every rank uses cuda:0 (rehearsal only; never a measurement)")
     ap.add_argument("--streams", type=int, default=3, help="contexts (own HIP stream + host thread each) that alternate batches")
+    ap.add_argument("--batches-per-call", type=int, default=1, help="consecutive reference batches handed to the library in one call "
+                    "(pseg_process_batches: every batch keeps its own background window; a step stays one batch of 200 frames)")
     args = ap.parse_args()
 
     import torch
@@ -81,18 +83,20 @@ def main():
     import queue
     import threading
     ns = max(1, args.streams)
-    segs = [Segmenter(H, W, max_frames=BATCH, device=local_rank) for _ in range(ns)]
+    bpc = max(1, args.batches_per_call)                      # batches per library call
+    segs = [Segmenter(H, W, max_frames=BATCH * bpc, device=local_rank) for _ in range(ns)]
     seg = segs[0]
     mask = seg.disk_mask(1200)
     cfg = synth.CONFIGS[args.workload]
     nb = max(1, min(args.batches, args.steps + args.warmup))
+    nb = ((nb + bpc - 1) // bpc) * bpc                       # whole groups of batches
     seed = 2 + 1000 * rank
-    stacks = []
-    for b in range(nb):
-        objs, off = synth.make_objects(BATCH, H, W, seed, frame0=b * BATCH, **cfg)
-        stacks.append(seg.synth_frames(BATCH, seed, objs, off, frame0=b * BATCH))
-    cleaned = [torch.empty((BATCH, H, W), dtype=torch.uint8, device=dev) for _ in range(ns)]
-    labels = [None if args.no_labels else torch.empty((BATCH, H, W), dtype=torch.int32, device=dev) for _ in range(ns)]
+    stacks = []                                              # nb / bpc resident groups of bpc consecutive batches each
+    for g in range(nb // bpc):
+        objs, off = synth.make_objects(BATCH * bpc, H, W, seed, frame0=g * bpc * BATCH, **cfg)
+        stacks.append(seg.synth_frames(BATCH * bpc, seed, objs, off, frame0=g * bpc * BATCH))
+    cleaned = [torch.empty((BATCH * bpc, H, W), dtype=torch.uint8, device=dev) for _ in range(ns)]
+    labels = [None if args.no_labels else torch.empty((BATCH * bpc, H, W), dtype=torch.int32, device=dev) for _ in range(ns)]
 
     gatherer = sharding.TableGatherer(device=cdev) if world > 1 else None
     wire = np.empty(256 << 20, np.uint8) if world > 1 else None     # reused by pack_table
@@ -100,11 +104,14 @@ def main():
     stats = dict(rows=0, saved=0, crop_bytes=0, contours=0, gather_s=0.0)
     lock = threading.Lock()
 
-    def step(i, k, timed, out_q=None):
-        """one batch through the fused hot path on context k"""
-        _, _, _, tab = segs[k].process(stacks[i % nb], mask=mask, cleaned=cleaned[k], labels=labels[k])
+    def call(c, nbat, k, timed, out_q=None):
+        """library call number c: nbat consecutive batches (steps) through the fused hot path on context k"""
+        grp = stacks[c % len(stacks)]
+        m = nbat * BATCH
+        _, _, _, tab = segs[k].process(grp[:m], mask=mask, cleaned=cleaned[k][:m], labels=None if labels[k] is None else labels[k][:m],
+                                       batch_len=BATCH)
         if out_q is not None:
-            out_q.put((i, tab))                              # packed and gathered by the main thread
+            out_q.put((c, tab))                              # packed and gathered by the main thread
         if timed:
             with lock:
                 stats["rows"] += tab.n_rows
@@ -112,38 +119,40 @@ def main():
                 stats["crop_bytes"] += tab.crop_bytes
                 stats["contours"] += int(tab.frame_n_contours.sum())
 
-    def run(first, count, timed):
-        """steps first..first+count-1, dealt round-robin to the contexts (one host thread each); the object
-        tables are gathered to rank 0 from the main thread, in step order, while later batches compute"""
+    def run(count, timed):
+        """count steps (batches) as calls of bpc batches (the last call takes the remainder), dealt round-robin to the
+        contexts (one host thread each); the object tables are gathered to rank 0 from the main thread, in call order,
+        while later batches compute"""
+        calls = [(c, min(bpc, count - c * bpc)) for c in range((count + bpc - 1) // bpc)]
         out_q = queue.Queue() if world > 1 else None
-        ths = [threading.Thread(target=lambda k=k: [step(i, k, timed, out_q) for i in range(first + k, first + count, ns)])
-               for k in range(ns)]
+        ths = [threading.Thread(target=lambda k=k: [call(c, nbat, k, timed, out_q) for c, nbat in calls[k::ns]]) for k in range(ns)]
         for t in ths:
             t.start()
         if world > 1:
-            # tables of GATHER_EVERY consecutive batches travel in one message: fewer, larger collectives
-            pending, fill = {}, 0
-            for want in range(first, first + count):
+            # tables of about GATHER_EVERY consecutive batches travel in one message: fewer, larger collectives
+            pending, fill, since = {}, 0, 0
+            for want, nbat in calls:
                 while want not in pending:
-                    i, tab = out_q.get()
-                    pending[i] = tab
+                    c, tab = out_q.get()
+                    pending[c] = tab
                 g0 = time.perf_counter()
-                blob = sharding.pack_table(pending.pop(want), frame_base=(rank * nb + want % nb) * BATCH, out=wire[fill:])
+                blob = sharding.pack_table(pending.pop(want), frame_base=(rank * nb + (want * bpc) % nb) * BATCH, out=wire[fill:])
                 fill += blob.size
-                if (want - first + 1) % GATHER_EVERY == 0 or want == first + count - 1:
+                since += nbat
+                if since >= GATHER_EVERY or want == calls[-1][0]:
                     gatherer.gather(wire[:fill])
-                    fill = 0
+                    fill, since = 0, 0
                 if timed:
                     stats["gather_s"] += time.perf_counter() - g0
         for t in ths:
             t.join()
 
-    run(0, args.warmup, False)
+    run(args.warmup, False)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    run(args.warmup, args.steps, True)
+    run(args.steps, True)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -154,9 +163,9 @@ def main():
         elapsed = float(t.item())
     # kernel-group durations for the roofline: HIP events on the library's stream, one context alone on the GPU
     # (with several contexts in flight the kernels of different batches overlap and share the bandwidth)
-    nprobe = min(4, args.steps)
+    nprobe = 3
     for i in range(nprobe):
-        step(args.warmup + i, 0, False)
+        call(i, bpc, 0, False)
         for k in GROUP_NAMES:
             group_ms[k] += seg.last_ms(k)
 
@@ -170,13 +179,14 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get(dom_name)
+            traffic = json.load(open(tpath)).get(dom_name)    # PMC bytes of a 200-frame launch (profiles/README.md)
+            traffic = traffic * bpc if traffic is not None else None      # a launch covers bpc batches; bytes are per frame
         except Exception:
             traffic = None
     if dom_name in GROUP_BYTES:
-        launch_bytes = GROUP_BYTES[dom_name] * BATCH
+        launch_bytes = GROUP_BYTES[dom_name] * BATCH * bpc
     else:   # sparse groups: their share of the path's compulsory bytes is the object payload only
-        launch_bytes = (stats["crop_bytes"] * 3 + stats["rows"] * 44 * 8) / max(args.steps, 1)
+        launch_bytes = (stats["crop_bytes"] * 3 + stats["rows"] * 44 * 8) / max(args.steps, 1) * bpc
     achieved = launch_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     out = {
         "metric": "frames/sec (2560x2560 uint8), hot path bg_correction+detection",
@@ -184,7 +194,7 @@ def main():
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": f"configs[1]: {nb * BATCH}-frame {args.workload} stack per GPU, batches of {BATCH}, bg window 12, "
-                               f"~{cfg['per_frame']} objects/frame, label map {'off' if args.no_labels else 'on'}",
+                               f"~{cfg['per_frame']} objects/frame, label map {'off' if args.no_labels else 'on'}, {bpc} batches per library call",
                    "frames_per_step": BATCH, "objects_per_frame": round(stats["contours"] / (args.steps * BATCH), 1),
                    "rows_per_frame": round(stats["rows"] / (args.steps * BATCH), 1),
                    "saved_per_frame": round(stats["saved"] / (args.steps * BATCH), 1)},
@@ -194,13 +204,14 @@ def main():
         "path": {"bytes_per_frame": PATH_BYTES_PER_FRAME if not args.no_labels else 2 * P,
                  "frac_of_hbm_peak_per_gpu": round(fps / world * (PATH_BYTES_PER_FRAME if not args.no_labels else 2 * P) / (HBM_PEAK_GBS * 1e9), 4),
                  "contexts": ns, "table_gather_ms_per_step_rank0": round(stats["gather_s"] / args.steps * 1e3, 3) if world > 1 else None,
-                 "group_ms_per_step_single_context": {GROUP_NAMES[k]: round(group_ms[k] / nprobe, 3) for k in GROUP_NAMES}},
+                 "batches_per_call": bpc,
+                 "group_ms_per_step_single_context": {GROUP_NAMES[k]: round(group_ms[k] / nprobe / bpc, 3) for k in GROUP_NAMES}},
     }
 
     if rank == 0 and world == 1 and args.cpu_frames >= 12:
         # the oracle is the timed CPU port here, never the product path
         nf = min(args.cpu_frames, BATCH)
-        sample = stacks[0][:nf].cpu().numpy()
+        sample = stacks[0][:nf].cpu().numpy()                # nf <= BATCH: inside the first batch
         hmask = mask.cpu().numpy()
         pb, pd = (int(v) for v in args.cpu_procs.split(","))
         if pb == 1 and pd == 1:

@@ -69,7 +69,7 @@ struct pseg_ctx {
     bool mask_counted = false;    // maskcnt already holds the number of mask == 255 pixels (fused background kernel)
     bool have_bits = false;       // threshold plane + masked sums already produced by the bg kernel
     DevBuf bounds, band_off, band_obj, trash, rp_small, rp_scratch;
-    int bounds_n = -1, bounds_emit = -1, bounds_chunks = -1;
+    int bounds_n = -1, bounds_emit = -1, bounds_chunks = -1, bounds_batch = -1;
     bool runs_old = false;        // wave-per-row run extraction (k_runs) instead of k_runs_quad (PSEG_RUNS_OLD)
     bool exclusive = true;        // the device part of a call holds the GPU's turn (PSEG_EXCLUSIVE=0: batches interleave freely)
     bool early_release = true;    // hand the turn on behind the label fill instead of behind the last kernel (PSEG_EARLY_RELEASE=0)
@@ -414,10 +414,11 @@ __device__ __forceinline__ void bg_step(BgRegs &R, uint2 *ring, const BgEmit &E,
     bg_emit<PAD>(E, old, px_split(old), t11, k - 11, k - 11 >= a && k < n - 1);
 }
 
-// grid = (ceil(P/2048), chunks); chunk c emits frames [bounds[c], bounds[c+1]).  PAD: the last block has lanes beyond the frame
-// (P % 2048 != 0).
+// grid = (ceil(P/2048), chunks); chunk c emits frames [bounds[c], bounds[c+1]) of the reference batch that ends at frame
+// bounds[chunks + 1 + c] (several batches in one launch: every batch is at least one chunk).  PAD: the last block has lanes
+// beyond the frame (P % 2048 != 0).
 template <bool PAD>
-__global__ __launch_bounds__(256, 4) void k_bg_stream(const uint8_t *__restrict__ frames, int n, size_t P, uint8_t *__restrict__ cleaned,
+__global__ __launch_bounds__(256, 4) void k_bg_stream(const uint8_t *__restrict__ frames, size_t P, uint8_t *__restrict__ cleaned,
                                                       const uint8_t *__restrict__ mask, int thr, uint8_t *__restrict__ bits8,
                                                       uint4 *__restrict__ partials, const int *__restrict__ bounds,
                                                       uint8_t *__restrict__ trash, uint32_t *__restrict__ maskpart)
@@ -427,6 +428,7 @@ __global__ __launch_bounds__(256, 4) void k_bg_stream(const uint8_t *__restrict_
     const bool act = strip * 8 < P;                         // padding lanes stay in the wave (DPP sums), load strip 0, store nothing
     if (!act) strip = 0;
     const int a = bounds[blockIdx.y], b = bounds[blockIdx.y + 1];
+    const int n = bounds[gridDim.y + 1 + blockIdx.y];        // end of the reference batch this chunk belongs to
     const int kend = (b == n) ? n - 1 : b + 10;
     BgEmit E;
     E.cleaned = cleaned; E.bits8 = bits8; E.partials = partials; E.P = P;
@@ -1624,18 +1626,26 @@ struct GpuTurn {
 // frames share one window, bg_correction.py:72).  n_emit < n_avail: the leading part of a batch cut for another GPU;
 // the rest is the forward halo (>= window - 1 frames), so no emitted frame reaches the clamp -- the kernels are simply
 // told the batch is one frame longer than what they may read.
+// batch_len > 0: the n_avail = n_emit frames are consecutive reference batches of batch_len frames (the last one may be
+// shorter); every batch gets its own end-of-batch window (segmenter.py:209-213 cuts the file list, bg_correction.py:72 clamps
+// inside a batch).
 static int run_bg(pseg_ctx *ctx, const uint8_t *frames, int n_avail, int n_emit, int n_bg_imgs, const uint8_t *mask, int thr,
-                  uint8_t *cleaned)
+                  uint8_t *cleaned, int batch_len = 0)
 {
     int NW = 2 * n_bg_imgs;                                   // bg_correction.py:65
     const bool part = n_emit < n_avail;
     const int n = n_emit;
-    if (n_bg_imgs < 1 || 2 * n_avail < NW) return fail(ctx, PSEG_ERR_ARG, "need n >= n_bg_imgs (reference raises IndexError below that)");
+    if (batch_len <= 0 || batch_len >= n_avail) batch_len = 0;
+    const int nbatch = batch_len ? (n_avail + batch_len - 1) / batch_len : 1;
+    const int last_len = batch_len ? n_avail - (nbatch - 1) * batch_len : n_avail;
+    if (batch_len && part) return fail(ctx, PSEG_ERR_ARG, "a part of a batch cannot be split into batches");
+    if (n_bg_imgs < 1 || 2 * last_len < NW || (batch_len && 2 * batch_len < NW))
+        return fail(ctx, PSEG_ERR_ARG, "need n >= n_bg_imgs (reference raises IndexError below that)");
     if (part && n_avail - n_emit < NW - 1) return fail(ctx, PSEG_ERR_ARG, "a part of a batch needs a forward halo of 2 * n_bg_imgs - 1 frames");
     const int n_kernel = part ? n_avail + 1 : n_avail;       // batch length as the kernels see it
     size_t P = ctx->P;
     unsigned nblk = nblocks(P / 8);
-    const bool stream = (NW == 12 && n_avail >= 12 && !ctx->force_generic);
+    const bool stream = (NW == 12 && last_len >= 12 && (!batch_len || batch_len >= 12) && !ctx->force_generic);
     unsigned npart = stream ? nblk * 4 : nblk;               // partial sums per frame: per wave / per block
     ENSURE(ctx->bits, (size_t)n * P / 8);
     ENSURE(ctx->partials, (size_t)n * npart * 4 * sizeof(uint32_t));
@@ -1644,32 +1654,45 @@ static int run_bg(pseg_ctx *ctx, const uint8_t *frames, int n_avail, int n_emit,
     int chunks = 1;
     if (stream) {
         ENSURE(ctx->trash, P + P / 8 + (size_t)npart * 16 + 256);
-        chunks = ctx->bg_chunks;
-        const int span = part ? n_emit : n_avail - 12;        // chunk starts lie in [0, span)
-        if (chunks > span) chunks = span;
-        if (chunks < 1) chunks = 1;
-        if (ctx->bounds_n != n_avail || ctx->bounds_emit != n_emit || ctx->bounds_chunks != chunks) {
-            std::vector<int> bnd(chunks + 1);
-            for (int c = 0; c < chunks; c++) bnd[c] = (int)((long long)c * span / chunks);
+        // chunk bounds [chunks + 1] followed by the end of the batch each chunk lies in [chunks]
+        std::vector<int> bnd;
+        if (batch_len) {
+            chunks = nbatch;
+            bnd.resize(2 * chunks + 1);
+            for (int c = 0; c < chunks; c++) { bnd[c] = c * batch_len; bnd[chunks + 1 + c] = (c + 1) * batch_len < n_avail ? (c + 1) * batch_len : n_avail; }
+            bnd[chunks] = n_avail;
+        } else {
+            chunks = ctx->bg_chunks;
+            const int span = part ? n_emit : n_avail - 12;    // chunk starts lie in [0, span)
+            if (chunks > span) chunks = span;
+            if (chunks < 1) chunks = 1;
+            bnd.resize(2 * chunks + 1);
+            for (int c = 0; c < chunks; c++) { bnd[c] = (int)((long long)c * span / chunks); bnd[chunks + 1 + c] = n_kernel; }
             bnd[chunks] = n_emit;
-            ENSURE(ctx->bounds, (size_t)(chunks + 1) * 4);
-            HIPCHK(hipMemcpyAsync(ctx->bounds.p, bnd.data(), (size_t)(chunks + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+        }
+        if (ctx->bounds_n != n_avail || ctx->bounds_emit != n_emit || ctx->bounds_chunks != chunks || ctx->bounds_batch != batch_len) {
+            ENSURE(ctx->bounds, bnd.size() * 4);
+            HIPCHK(hipMemcpyAsync(ctx->bounds.p, bnd.data(), bnd.size() * 4, hipMemcpyHostToDevice, ctx->stream));
             HIPCHK(hipStreamSynchronize(ctx->stream));
-            ctx->bounds_n = n_avail; ctx->bounds_emit = n_emit; ctx->bounds_chunks = chunks;
+            ctx->bounds_n = n_avail; ctx->bounds_emit = n_emit; ctx->bounds_chunks = chunks; ctx->bounds_batch = batch_len;
         }
     }
     HIPCHK(hipEventRecord(ctx->ev[0], ctx->stream));
     if (stream && P % 2048 == 0)
-        hipLaunchKernelGGL(k_bg_stream<false>, dim3(nblk, chunks), dim3(256), 0, ctx->stream, frames, n_kernel, P, cleaned, mask, thr,
+        hipLaunchKernelGGL(k_bg_stream<false>, dim3(nblk, chunks), dim3(256), 0, ctx->stream, frames, P, cleaned, mask, thr,
                            (uint8_t *)ctx->bits.p, (uint4 *)ctx->partials.p, (const int *)ctx->bounds.p, (uint8_t *)ctx->trash.p,
                            (uint32_t *)ctx->maskpart.p);
     else if (stream)
-        hipLaunchKernelGGL(k_bg_stream<true>, dim3(nblk, chunks), dim3(256), 0, ctx->stream, frames, n_kernel, P, cleaned, mask, thr,
+        hipLaunchKernelGGL(k_bg_stream<true>, dim3(nblk, chunks), dim3(256), 0, ctx->stream, frames, P, cleaned, mask, thr,
                            (uint8_t *)ctx->bits.p, (uint4 *)ctx->partials.p, (const int *)ctx->bounds.p, (uint8_t *)ctx->trash.p,
                            (uint32_t *)ctx->maskpart.p);
     else
-        hipLaunchKernelGGL(k_bg_generic, dim3(nblk, n), dim3(256), 0, ctx->stream, frames, n_kernel, NW, P, cleaned, mask, thr,
-                           (uint8_t *)ctx->bits.p, (uint32_t *)ctx->partials.p);
+        for (int c = 0; c < nbatch; c++) {                   // the re-reading kernel takes one batch per launch
+            const size_t f0 = (size_t)c * (batch_len ? batch_len : 0);
+            const int nc = batch_len ? ((c + 1) * batch_len < n_avail ? batch_len : last_len) : n;
+            hipLaunchKernelGGL(k_bg_generic, dim3(nblk, nc), dim3(256), 0, ctx->stream, frames + f0 * P, batch_len ? nc : n_kernel, NW, P,
+                               cleaned + f0 * P, mask, thr, (uint8_t *)ctx->bits.p + f0 * (P / 8), (uint32_t *)ctx->partials.p + f0 * npart * 4);
+        }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
     hipLaunchKernelGGL(k_reduce_partials, dim3(n), dim3(1024), 0, ctx->stream, (const uint32_t *)ctx->partials.p, (int)npart,
@@ -2044,9 +2067,9 @@ extern "C" int pseg_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t 
     return PSEG_OK;
 }
 
-extern "C" int pseg_process_part(pseg_ctx *ctx, const uint8_t *frames, int n_avail, int n_emit, int n_bg_imgs, const uint8_t *mask,
-                                 int threshold, double min_area_to_segment, double min_area_to_save, uint8_t *cleaned,
-                                 double *mean_std, uint8_t *valid, int32_t *labels, pseg_table *out)
+static int process_impl(pseg_ctx *ctx, const uint8_t *frames, int n_avail, int n_emit, int batch_len, int n_bg_imgs, const uint8_t *mask,
+                        int threshold, double min_area_to_segment, double min_area_to_save, uint8_t *cleaned,
+                        double *mean_std, uint8_t *valid, int32_t *labels, pseg_table *out)
 {
     int r = check_batch(ctx, n_avail);
     if (r) return r;
@@ -2055,7 +2078,7 @@ extern "C" int pseg_process_part(pseg_ctx *ctx, const uint8_t *frames, int n_ava
     const int n = n_emit;
     GpuTurn turn(ctx);
     HIPCHK(hipEventRecord(ctx->ev[6], ctx->stream));
-    r = run_bg(ctx, frames, n_avail, n_emit, n_bg_imgs, mask, threshold, cleaned);
+    r = run_bg(ctx, frames, n_avail, n_emit, n_bg_imgs, mask, threshold, cleaned, batch_len);
     if (r) return r;
     r = run_detect(ctx, cleaned, cleaned, mask, n, min_area_to_segment, min_area_to_save, labels, out);
     if (r) return r;
@@ -2069,12 +2092,29 @@ extern "C" int pseg_process_part(pseg_ctx *ctx, const uint8_t *frames, int n_ava
     return PSEG_OK;
 }
 
+extern "C" int pseg_process_part(pseg_ctx *ctx, const uint8_t *frames, int n_avail, int n_emit, int n_bg_imgs, const uint8_t *mask,
+                                 int threshold, double min_area_to_segment, double min_area_to_save, uint8_t *cleaned,
+                                 double *mean_std, uint8_t *valid, int32_t *labels, pseg_table *out)
+{
+    return process_impl(ctx, frames, n_avail, n_emit, 0, n_bg_imgs, mask, threshold, min_area_to_segment, min_area_to_save, cleaned,
+                        mean_std, valid, labels, out);
+}
+
 extern "C" int pseg_process(pseg_ctx *ctx, const uint8_t *frames, int n, int n_bg_imgs, const uint8_t *mask, int threshold,
                             double min_area_to_segment, double min_area_to_save, uint8_t *cleaned, double *mean_std,
                             uint8_t *valid, int32_t *labels, pseg_table *out)
 {
-    return pseg_process_part(ctx, frames, n, n, n_bg_imgs, mask, threshold, min_area_to_segment, min_area_to_save, cleaned, mean_std,
-                             valid, labels, out);
+    return process_impl(ctx, frames, n, n, 0, n_bg_imgs, mask, threshold, min_area_to_segment, min_area_to_save, cleaned, mean_std,
+                        valid, labels, out);
+}
+
+extern "C" int pseg_process_batches(pseg_ctx *ctx, const uint8_t *frames, int n, int batch_len, int n_bg_imgs, const uint8_t *mask,
+                                    int threshold, double min_area_to_segment, double min_area_to_save, uint8_t *cleaned,
+                                    double *mean_std, uint8_t *valid, int32_t *labels, pseg_table *out)
+{
+    if (batch_len < 1) return ctx ? fail(ctx, PSEG_ERR_ARG, "batch_len must be positive") : PSEG_ERR_ARG;
+    return process_impl(ctx, frames, n, n, batch_len, n_bg_imgs, mask, threshold, min_area_to_segment, min_area_to_save, cleaned,
+                        mean_std, valid, labels, out);
 }
 
 extern "C" int pseg_fetch_crops(pseg_ctx *ctx, uint8_t *raw, uint8_t *masked, uint8_t *mask)

@@ -171,9 +171,11 @@ class Segmenter:
         return self._table(t, fetch_crops)
 
     def process(self, frames, n_bg_imgs=6, mask=None, threshold=10, min_area_to_segment=10.0, min_area_to_save=400.0,
-                cleaned=None, labels=None, fetch_crops=False, want_table=True, n_emit=None):
+                cleaned=None, labels=None, fetch_crops=False, want_table=True, n_emit=None, batch_len=None):
         """Fused hot path over one batch.  ``n_emit`` < len(frames): ``frames`` is the leading part of a batch plus its
-        forward halo (sharding.plan_ranges); only the first n_emit frames are processed and returned."""
+        forward halo (sharding.plan_ranges); only the first n_emit frames are processed and returned.
+        ``batch_len``: ``frames`` holds several consecutive reference batches of that many frames (the last may be
+        shorter), each background-corrected inside its own batch; one table over all frames."""
         import torch
         n_avail = frames.shape[0]
         n = n_avail if n_emit is None else int(n_emit)
@@ -187,9 +189,17 @@ class Segmenter:
         valid = np.zeros(n, np.uint8)
         t = _lib.Table()
         torch.cuda.current_stream(frames.device).synchronize()
-        self._chk(self.L.pseg_process_part(self.h, frames.data_ptr(), n_avail, n, n_bg_imgs, None if mask is None else mask.data_ptr(),
-                                           int(threshold), float(min_area_to_segment), float(min_area_to_save), cleaned.data_ptr(),
-                                           ms.ctypes.data, valid.ctypes.data, None if labels is None else labels.data_ptr(), C.byref(t)))
+        if batch_len is not None and batch_len < n_avail:
+            if n != n_avail:
+                raise PsegError("n_emit and batch_len exclude each other")
+            self._chk(self.L.pseg_process_batches(self.h, frames.data_ptr(), n_avail, int(batch_len), n_bg_imgs,
+                                                  None if mask is None else mask.data_ptr(), int(threshold), float(min_area_to_segment),
+                                                  float(min_area_to_save), cleaned.data_ptr(), ms.ctypes.data, valid.ctypes.data,
+                                                  None if labels is None else labels.data_ptr(), C.byref(t)))
+        else:
+            self._chk(self.L.pseg_process_part(self.h, frames.data_ptr(), n_avail, n, n_bg_imgs, None if mask is None else mask.data_ptr(),
+                                               int(threshold), float(min_area_to_segment), float(min_area_to_save), cleaned.data_ptr(),
+                                               ms.ctypes.data, valid.ctypes.data, None if labels is None else labels.data_ptr(), C.byref(t)))
         tab = self._table(t, fetch_crops) if want_table else None
         return cleaned, ms, valid, tab
 

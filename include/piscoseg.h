@@ -113,6 +113,15 @@ int pseg_process_part(pseg_ctx *ctx, const uint8_t *frames, int n_avail, int n_e
                       const uint8_t *mask, int threshold, double min_area_to_segment, double min_area_to_save,
                       uint8_t *cleaned, double *mean_std, uint8_t *valid, int32_t *labels, pseg_table *out);
 
+/* Several consecutive reference batches in one call: frames [dev] u8[n][H][W] = the batches run_segmenter would cut
+ * (segmenter.py:209-213: batch_len = 200 files, the last batch takes the remainder), each background-corrected with its own
+ * window clamp (bg_correction.py:72) exactly as separate pseg_process calls would, then detected together (frames are
+ * independent from there on).  One table, frame indices 0 .. n-1 across the batches.  Every batch needs >= n_bg_imgs
+ * frames (as the reference).  Fewer, larger launches: the labelling kernels are latency-bound per launch. */
+int pseg_process_batches(pseg_ctx *ctx, const uint8_t *frames, int n, int batch_len, int n_bg_imgs, const uint8_t *mask,
+                         int threshold, double min_area_to_segment, double min_area_to_save, uint8_t *cleaned,
+                         double *mean_std, uint8_t *valid, int32_t *labels, pseg_table *out);
+
 /* Copy the three packed crop planes of the last detection to host buffers of crop_bytes each
  * (any may be NULL).  Replaces the arrays handed to cv.imwrite (detection.py:251-253). */
 int pseg_fetch_crops(pseg_ctx *ctx, uint8_t *raw, uint8_t *masked, uint8_t *mask);

@@ -358,3 +358,51 @@ def test_contexts_taking_turns_give_the_single_context_results():
             assert np.array_equal(g[key], w[key], equal_nan=(key in ("props", "mean"))), (i, key)
         for plane in w["crops"]:
             assert np.array_equal(g["crops"][plane], w["crops"][plane]), (i, plane)
+
+
+@pytest.mark.parametrize("n,batch_len,generic", [(42, 14, "0"), (40, 14, "0"), (26, 13, "0"), (30, 12, "1")])
+def test_several_batches_in_one_call_equal_separate_calls(monkeypatch, n, batch_len, generic):
+    """pseg_process_batches: consecutive reference batches (segmenter.py:209-213), each with its own window clamp
+    (bg_correction.py:72), detected together -- the same cleaned frames, labels and table rows as one call per batch; the
+    first batch is also checked against the oracle."""
+    import torch
+    from imageprocessing_amd.engine import Segmenter
+    monkeypatch.setenv("PSEG_BG_GENERIC", generic)
+    H, W = 192, 256
+    seg = Segmenter(H, W, max_frames=n, device=0)
+    stack, _, _ = _stack(n, H, W, 77, per_frame=12, dmin=25, dmax=500)
+    stack[batch_len + 2] = 60                                # a corrupt frame in the second batch
+    mask = helpers.make_disk(H, W, 90)
+    dmask = torch.from_numpy(mask).cuda()
+    dev = torch.from_numpy(stack).cuda()
+    labels = torch.empty((n, H, W), dtype=torch.int32, device="cuda")
+    cleaned, ms, valid, tab = seg.process(dev, mask=dmask, labels=labels, fetch_crops=True, batch_len=batch_len)
+    whole = dict(cleaned=cleaned.cpu().numpy(), labels=labels.cpu().numpy(), ms=ms.copy(), valid=valid.copy(),
+                 rows=np.stack([tab.frame, tab.c, tab.label, tab.x, tab.y, tab.w, tab.h, tab.saved.astype(np.int32)]).copy(),
+                 area=tab.area.copy(), props=tab.saved_props.copy(), off=tab.frame_row_offset.copy(),
+                 crops={k: v.copy() for k, v in tab.crops.items()}, crop_offset=tab.crop_offset.copy())
+    row0 = s0 = 0
+    for b0 in range(0, n, batch_len):
+        b1 = min(b0 + batch_len, n)
+        lab = torch.empty((b1 - b0, H, W), dtype=torch.int32, device="cuda")
+        c1, ms1, v1, t1 = seg.process(dev[b0:b1], mask=dmask, labels=lab, fetch_crops=True)
+        assert np.array_equal(v1, whole["valid"][b0:b1]) and np.array_equal(ms1, whole["ms"][b0:b1])
+        good = v1.astype(bool)
+        assert np.array_equal(c1.cpu().numpy()[good], whole["cleaned"][b0:b1][good])
+        assert np.array_equal(lab.cpu().numpy()[good], whole["labels"][b0:b1][good])
+        nr, ns = t1.n_rows, len(t1.saved_row)
+        rows1 = np.stack([t1.frame + b0, t1.c, t1.label, t1.x, t1.y, t1.w, t1.h, t1.saved.astype(np.int32)])
+        assert np.array_equal(rows1, whole["rows"][:, row0:row0 + nr]), f"batch at {b0}"
+        assert np.array_equal(t1.area, whole["area"][row0:row0 + nr])
+        assert np.array_equal(t1.saved_props, whole["props"][s0:s0 + ns], equal_nan=True)
+        assert np.array_equal(t1.frame_row_offset + row0, whole["off"][b0:b1 + 1])
+        c0 = whole["crop_offset"][s0]
+        for plane, v in t1.crops.items():
+            assert np.array_equal(v, whole["crops"][plane][c0:c0 + t1.crop_bytes]), plane
+        if b0 == 0:
+            dets = helpers.oracle_detect(helpers.oracle_bgcorrect(stack[b0:b1]), mask)
+            helpers.compare_table(t1, dets, H, W, labels=lab.cpu().numpy())
+        row0 += nr
+        s0 += ns
+    assert row0 == whole["rows"].shape[1] and row0 > 50
+    seg.close()
