@@ -8,7 +8,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 ev = [(int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].split('(')[0].replace('void ', '')) for r in rows
       if 'k_synth' not in r['Kernel_Name']]
 ev.sort()
-bgs = [i for i, e in enumerate(ev) if e[2].startswith('k_bg_stream')]
+bgs = [i for i, e in enumerate(ev) if 'k_bg_stream' in e[2]]
 a, b = bgs[4], bgs[-2]
 nst = len(bgs) - 2 - 4
 seg = ev[a:b]
