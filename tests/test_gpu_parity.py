@@ -406,3 +406,72 @@ def test_several_batches_in_one_call_equal_separate_calls(monkeypatch, n, batch_
         s0 += ns
     assert row0 == whole["rows"].shape[1] and row0 > 50
     seg.close()
+
+
+@pytest.mark.parametrize("W", [64, 704, 3072, 4096])
+def test_run_extraction_for_other_row_lengths(gpu_seg_factory, W):
+    """k_runs_quad gives a lane a quarter of the row's 64-bit words: rows of 1 word (three idle lanes per row), 11 words
+    (uneven quarters), 48 words (the 16-word variant) and 64 words (its limit) -- runs crossing the lane boundaries, full
+    rows, and sparse specks, against the oracle's contour trace."""
+    import torch
+    H, n = 40, 3
+    seg = gpu_seg_factory(H, W)
+    rng = np.random.default_rng(W)
+    cleaned = np.full((n, H, W), 255, np.uint8)
+    q = max(1, (W // 64 + 3) // 4) * 64                      # pixels per lane
+    for f in range(n):
+        img = cleaned[f]
+        img[3, :] = 20                                       # a full row
+        for k in range(1, 4):                                # runs straddling every lane boundary of the row
+            x = min(k * q, W - 1)
+            img[6 + 2 * k, max(0, x - 37):min(W, x + 45)] = 70
+        img[15:19, max(0, W - 30):W] = 10                    # ends at the right edge
+        img[15:19, 0:min(W, 25)] = 10                        # starts at the left edge
+        if W >= 704:
+            img[22:34, 70:640] = rng.integers(0, 230, (12, 570), dtype=np.uint8)
+        img[rng.random((H, W)) < 0.004] = 0
+    items = [(cleaned[f], cleaned[f], [100.0, 50.0], f"r_{f:03d}.png") for f in range(n)]
+    dets = helpers.oracle_detect(items, None, min_area_to_segment=2, min_area_to_save=40, mask_img=False)
+    labels = torch.empty((n, H, W), dtype=torch.int32, device="cuda")
+    tab = seg.detect(torch.from_numpy(cleaned).cuda(), min_area_to_segment=2, min_area_to_save=40, labels=labels, fetch_crops=True)
+    assert tab.n_rows > 5
+    helpers.compare_table(tab, dets, H, W, labels=labels.cpu().numpy())
+
+
+@pytest.mark.parametrize("env", [{"PSEG_EXCLUSIVE": "0"}, {"PSEG_EARLY_RELEASE": "0"}, {"PSEG_RUNS_OLD": "1"}])
+def test_switches_do_not_change_results(monkeypatch, env):
+    """The scheduling and kernel-choice switches of INTEGRATION.md change timing only: two contexts on two threads give
+    the oracle's table under each of them."""
+    import threading
+    import torch
+    from imageprocessing_amd.engine import Segmenter
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    H, W, n = 128, 256, 14
+    mask = helpers.make_disk(H, W, 60)
+    dmask = torch.from_numpy(mask).cuda()
+    stacks = [_stack(n, H, W, 90 + k, per_frame=10, dmin=20, dmax=300)[0] for k in range(2)]
+    segs = [Segmenter(H, W, max_frames=n, device=0) for _ in range(2)]
+    res, errors = {}, []
+
+    def worker(k):
+        try:
+            for _ in range(3):
+                labels = torch.empty((n, H, W), dtype=torch.int32, device="cuda")
+                _, _, _, tab = segs[k].process(torch.from_numpy(stacks[k]).cuda(), mask=dmask, labels=labels, fetch_crops=True)
+                res[k] = (tab, labels.cpu().numpy())
+        except Exception as e:
+            errors.append(e)
+
+    ths = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(120)
+        assert not t.is_alive()
+    assert not errors, errors
+    for k in range(2):
+        dets = helpers.oracle_detect(helpers.oracle_bgcorrect(stacks[k]), mask)
+        helpers.compare_table(res[k][0], dets, H, W, labels=res[k][1])
+    for s in segs:
+        s.close()
