@@ -49,7 +49,7 @@ struct pseg_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     std::string err;
-    hipEvent_t ev[8] = {};
+    hipEvent_t ev[9] = {};         // 0..7 time the kernel groups, 8 marks the run count on its way to the host
     float ms[6] = {};
     // dense workspaces
     DevBuf bits, partials, maskpart, rowspans;
@@ -680,8 +680,11 @@ __global__ __launch_bounds__(256) void k_runs(SegState S, int nrows)
 // so the carry between words stays in the lane and a row costs a handful of instructions per word instead of a wave-wide
 // scan per row.  Starts are rare (about one word in fifty holds one), the walk over the words is the whole cost.
 template <bool FILL, int WPL>
-__global__ __launch_bounds__(256) void k_runs_quad(SegState S, int nrows, int wpl)
+__global__ __launch_bounds__(256) void k_runs_quad(SegState S, int nrows, int wpl, uint32_t cap)
 {
+    // FILL is launched before the host knows the run count, into the buffers of the previous batch: nothing is written
+    // when the runs do not fit (cap = entries of run_x / run_fy; the host then grows the buffers and launches again)
+    if (FILL && S.framebase[S.F] > cap) return;
     const int lane = threadIdx.x & 63, part = lane & 3;
     const int row = (blockIdx.x * 4 + (int)(threadIdx.x >> 6)) * RUNS_RPW + (lane >> 2);
     bool want = row < nrows;
@@ -1839,13 +1842,22 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
     const int runs_wpl = (S.WW + 3) / 4;                     // words per lane of k_runs_quad
     const dim3 runs_grid(nblocks((size_t)n * H, 4 * RUNS_RPW));
     if (ctx->runs_old || runs_wpl > 16) hipLaunchKernelGGL(k_runs<false>, runs_grid, dim3(256), 0, st, S, n * H);       // rows wider than 4096 px
-    else if (runs_wpl > 10) hipLaunchKernelGGL((k_runs_quad<false, 16>), runs_grid, dim3(256), 0, st, S, n * H, runs_wpl);
-    else hipLaunchKernelGGL((k_runs_quad<false, 10>), runs_grid, dim3(256), 0, st, S, n * H, runs_wpl);
+    else if (runs_wpl > 10) hipLaunchKernelGGL((k_runs_quad<false, 16>), runs_grid, dim3(256), 0, st, S, n * H, runs_wpl, 0u);
+    else hipLaunchKernelGGL((k_runs_quad<false, 10>), runs_grid, dim3(256), 0, st, S, n * H, runs_wpl, 0u);
     hipLaunchKernelGGL(k_scan_rows, dim3(n), dim3(256), 0, st, S, ftot, S.framebase + n + 1);
     hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(256), 0, st, (const uint32_t *)ftot, S.framebase, n, 1, 1);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(ctx->pin_nfg.p, S.framebase + n, 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipEventRecord(ctx->ev[8], st));
+    // the run tables are filled while the host waits for the count, into the buffers as they stand (see k_runs_quad)
+    const size_t spec_bytes = ctx->run_x.bytes < ctx->run_fy.bytes ? ctx->run_x.bytes : ctx->run_fy.bytes;
+    const uint32_t spec_cap = (ctx->runs_old || runs_wpl > 16) ? 0u : (uint32_t)(spec_bytes / 4 > 0x3fffffffu ? 0x3fffffffu : spec_bytes / 4);
+    if (spec_cap > 0) {
+        S.run_x = (uint32_t *)ctx->run_x.p; S.run_fy = (uint32_t *)ctx->run_fy.p;
+        if (runs_wpl > 10) hipLaunchKernelGGL((k_runs_quad<true, 16>), runs_grid, dim3(256), 0, st, S, n * H, runs_wpl, spec_cap);
+        else hipLaunchKernelGGL((k_runs_quad<true, 10>), runs_grid, dim3(256), 0, st, S, n * H, runs_wpl, spec_cap);
+    }
+    HIPCHK(hipEventSynchronize(ctx->ev[8]));
     const uint32_t nfg_u = ((const volatile uint32_t *)ctx->pin_nfg.p)[0], bandmax = ((const volatile uint32_t *)ctx->pin_nfg.p)[1];
     if (nfg_u > 0x3fffffffu) return fail(ctx, PSEG_ERR_CAPACITY, "too many foreground runs");
     const int nfg = (int)nfg_u, nbg = nfg + n * H;
@@ -1863,9 +1875,10 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
     S.extrank = (int32_t *)ctx->extrank.p; S.keptrank = (int32_t *)ctx->keptrank.p; S.savedrank = (int32_t *)ctx->savedrank.p;
     int32_t *objlabel = (int32_t *)ctx->objlabel.p, *objflag = (int32_t *)ctx->objflag.p;
 
+    const bool runs_done = spec_cap > 0 && nfg_u <= spec_cap;     // (the buffers were not reallocated then: cap <= their size)
     if (nfg > 0 && (ctx->runs_old || runs_wpl > 16)) hipLaunchKernelGGL(k_runs<true>, runs_grid, dim3(256), 0, st, S, n * H);
-    else if (nfg > 0 && runs_wpl > 10) hipLaunchKernelGGL((k_runs_quad<true, 16>), runs_grid, dim3(256), 0, st, S, n * H, runs_wpl);
-    else if (nfg > 0) hipLaunchKernelGGL((k_runs_quad<true, 10>), runs_grid, dim3(256), 0, st, S, n * H, runs_wpl);
+    else if (nfg > 0 && !runs_done && runs_wpl > 10) hipLaunchKernelGGL((k_runs_quad<true, 16>), runs_grid, dim3(256), 0, st, S, n * H, runs_wpl, 0xffffffffu);
+    else if (nfg > 0 && !runs_done) hipLaunchKernelGGL((k_runs_quad<true, 10>), runs_grid, dim3(256), 0, st, S, n * H, runs_wpl, 0xffffffffu);
     if (bandmax <= BAND_CAP && !ctx->no_bands) {
         // bands of BAND_H rows are labelled in LDS; the global kernels only unite across the band boundaries
         hipLaunchKernelGGL(k_band_label, dim3((H + BAND_H - 1) / BAND_H, n), dim3(256), 0, st, S);
