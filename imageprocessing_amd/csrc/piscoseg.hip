@@ -1090,7 +1090,9 @@ __global__ void k_saved_geo(const uint32_t *n_saved_p, const int32_t *saved_row,
     sz[3 * g + 2] = (unsigned long long)((h + rpb - 1) / rpb);
     if (h > totals[3]) atomicMax(&totals[3], (long long)h);    // tallest saved object: LDS size of k_convex
 }
-// exclusive scans of the three size columns by one block of 1024 threads; out[k][0..n]
+// exclusive scans of the three size columns by one block of 1024 threads; out[k][0..n].  A thread takes 8 consecutive
+// objects (one pass of wave / block scans per 8192 objects)
+#define SCAN_IPT 8
 __global__ __launch_bounds__(1024) void k_scan_sizes(const unsigned long long *sz, const uint32_t *n_p, long long *crop_off,
                                                       long long *bits_off, long long *band_off, long long *totals)
 {
@@ -1100,12 +1102,14 @@ __global__ __launch_bounds__(1024) void k_scan_sizes(const unsigned long long *s
     if (threadIdx.x < 3) carry[threadIdx.x] = 0;
     __syncthreads();
     long long *outp[3] = {crop_off, bits_off, band_off};
-    for (int base = 0; base < n; base += 1024) {
-        const int i = base + threadIdx.x;
-        unsigned long long v[3] = {0, 0, 0}, inc[3];
-        if (i < n) for (int k = 0; k < 3; k++) v[k] = sz[3 * (size_t)i + k];
-        for (int k = 0; k < 3; k++) {                        // inclusive scan inside the wave
-            unsigned long long x = v[k];
+    for (int base = 0; base < n; base += 1024 * SCAN_IPT) {
+        const int i0 = base + threadIdx.x * SCAN_IPT;
+        unsigned long long v[SCAN_IPT][3], tot[3] = {0, 0, 0}, inc[3];
+#pragma unroll
+        for (int j = 0; j < SCAN_IPT; j++)
+            for (int k = 0; k < 3; k++) { v[j][k] = (i0 + j < n) ? sz[3 * (size_t)(i0 + j) + k] : 0; tot[k] += v[j][k]; }
+        for (int k = 0; k < 3; k++) {                        // inclusive scan of the thread totals inside the wave
+            unsigned long long x = tot[k];
             for (int o = 1; o < 64; o <<= 1) { unsigned long long t = __shfl_up(x, o, 64); if (lane >= o) x += t; }
             inc[k] = x;
         }
@@ -1113,7 +1117,11 @@ __global__ __launch_bounds__(1024) void k_scan_sizes(const unsigned long long *s
         __syncthreads();
         unsigned long long pre[3] = {carry[0], carry[1], carry[2]};
         for (int w = 0; w < wv; w++) for (int k = 0; k < 3; k++) pre[k] += wtot[w][k];
-        if (i < n) for (int k = 0; k < 3; k++) outp[k][i] = (long long)(pre[k] + inc[k] - v[k]);
+        for (int k = 0; k < 3; k++) {
+            unsigned long long run = pre[k] + inc[k] - tot[k];
+#pragma unroll
+            for (int j = 0; j < SCAN_IPT; j++) { if (i0 + j < n) outp[k][i0 + j] = (long long)run; run += v[j][k]; }
+        }
         __syncthreads();
         if (threadIdx.x == 1023) for (int k = 0; k < 3; k++) carry[k] = pre[k] + inc[k];
         __syncthreads();
