@@ -1068,6 +1068,13 @@ __global__ __launch_bounds__(256) void k_label_fill(SegState S, const int32_t *_
 #ifndef CROP_THREADS
 #define CROP_THREADS 256
 #endif
+#ifndef CROP_UNROLL
+#define CROP_UNROLL 4
+#endif
+#ifndef CROP_TPR
+#define CROP_TPR 4                   // threads that share the runs of one row while the mask is painted (64 rows at a time;
+                                     // 16 / 8 / 2 threads per row: 0.384 / 0.351 / 0.338 ms for the crop group against 0.334 ms)
+#endif
 #define CROP_LDS_WORDS 1536          // mask words of a band + 2 halo rows on each side (frames up to 8192 px wide)
 __host__ __device__ inline int crop_rows_per_band(int w)
 {
@@ -1190,7 +1197,7 @@ __global__ __launch_bounds__(CROP_THREADS) void k_crops_sums(SegState S, int n_s
     } else {
         // 16 threads per row walk the row's runs; a run paints itself and the gap on its left when the object that fills
         // them (ext / gapl) is saved and was iterated at or before this one.  Two dependent global loads per row.
-        const int sub = threadIdx.x & 15, x_lo = bx, x_hi = bx + w - 1;
+        const int sub = threadIdx.x & (CROP_TPR - 1), x_lo = bx, x_hi = bx + w - 1;
         auto paint = [&](uint32_t *mrow, int xa, int xb) {
             int la = (xa > x_lo ? xa : x_lo) - bx, lb = (xb < x_hi ? xb : x_hi) - bx;
             for (int wd = la >> 5; wd <= (lb >> 5); wd++) {
@@ -1199,12 +1206,12 @@ __global__ __launch_bounds__(CROP_THREADS) void k_crops_sums(SegState S, int n_s
                 atomicOr(&mrow[wd], m);
             }
         };
-        for (int yl = threadIdx.x >> 4; yl < nrows + 4; yl += CROP_THREADS / 16) {
+        for (int yl = threadIdx.x / CROP_TPR; yl < nrows + 4; yl += CROP_THREADS / CROP_TPR) {
             const int yy = r0 - 2 + yl;
             if (yy < 0 || yy >= h) continue;
             const int rs = seg_rowstart(S, f, by + yy), n = seg_rowcount(S, f, by + yy);
             uint32_t *mrow = mbuf + yl * wpr;
-            for (int j = sub; j < n; j += 16) {
+            for (int j = sub; j < n; j += CROP_TPR) {
                 const int r = rs + j;
                 const uint32_t rx = S.run_x[r];
                 const int xs = (int)(rx & 0xffffu), xe = (int)(rx >> 16);
@@ -1242,7 +1249,7 @@ __global__ __launch_bounds__(CROP_THREADS) void k_crops_sums(SegState S, int n_s
         // bytes it shares with the neighbour from the sums.
         const int cpr = (w + 3) >> 2, nitem = nrows * cpr;
         const float rcp = 1.0f / (float)cpr;
-#pragma unroll 4
+#pragma unroll CROP_UNROLL
         for (int p = threadIdx.x; p < nitem; p += CROP_THREADS) {
             int yl = (int)((float)p * rcp);               // p / cpr, corrected below (p < 2^24)
             int c = p - yl * cpr;
