@@ -1414,7 +1414,8 @@ __global__ __launch_bounds__(CROP_THREADS) void k_crops_sums(SegState S, int n_s
 // cross products: |dX| < 2^15, |dR'| < 2^14 for the heights the LDS admits; collinear points are dropped.
 // Dynamic LDS: 56 bytes per row of the tallest object served by the launch (the host launches one size class per
 // call so that small objects keep a high occupancy).
-#define HULL_LDS_PER_ROW 56
+#define HULL_LDS_PER_ROW 28
+typedef short hull_t;                // profile values (|X| <= 2 * 8191 + 1, sentinels +-20000) and list links (< 2 * 2700 + 2) fit 16 bits
 template <bool LOWER>
 __device__ __forceinline__ bool hull_drop(int ra, int va, int rb, int vb, int rc, int vc)   // b is no strict vertex between a and c
 {
@@ -1428,7 +1429,7 @@ __device__ __forceinline__ void hull_wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 template <bool LOWER>
-__device__ __forceinline__ void hull_chain(const int *pv, int np, volatile int *nxt, volatile int *prv, int *bound, int h, int lane)
+__device__ __forceinline__ void hull_chain(const hull_t *pv, int np, volatile hull_t *nxt, volatile hull_t *prv, hull_t *bound, int h, int lane)
 {
     const int seg = (np + 63) >> 6;
     {   // strict hull of the lane's piece [s0, s1)
@@ -1443,7 +1444,7 @@ __device__ __forceinline__ void hull_chain(const int *pv, int np, volatile int *
                     if (p < 0 || !hull_drop<LOWER>(p, pv[p], top, vtop, c, vc)) break;
                     top = p; vtop = pv[p];
                 }
-                prv[c] = top; nxt[top] = c; top = c; vtop = vc;
+                prv[c] = (hull_t)top; nxt[top] = (hull_t)c; top = c; vtop = vc;
             }
             nxt[top] = -1;
         }
@@ -1461,13 +1462,13 @@ __device__ __forceinline__ void hull_chain(const int *pv, int np, volatile int *
                 while (nv >= 0 && hull_drop<LOWER>(u, vu, v, vv, nv, pv[nv])) { v = nv; vv = pv[v]; nv = nxt[v]; moved = true; }
                 if (!moved) break;
             }
-            nxt[u] = v; prv[v] = u;
+            nxt[u] = (hull_t)v; prv[v] = (hull_t)u;
         }
     }
     hull_wave_sync();
-    int *vl = (int *)prv;                                   // vertex array over the (now dead) back links: vl[k] sits at or before vertex k
+    hull_t *vl = (hull_t *)prv;                             // vertex array over the (now dead) back links: vl[k] sits at or before vertex k
     int nv = 0;
-    if (lane == 0) for (int i = 0; i >= 0; i = nxt[i]) vl[nv++] = i;
+    if (lane == 0) for (int i = 0; i >= 0; i = nxt[i]) vl[nv++] = (hull_t)i;
     nv = __builtin_amdgcn_readfirstlane(nv);
     hull_wave_sync();
     for (int r = lane; r < h; r += 64) {                    // pixel row r = profile index 2r+1
@@ -1479,7 +1480,7 @@ __device__ __forceinline__ void hull_chain(const int *pv, int np, volatile int *
         const int num = xa * den + (xb - xa) * (i - ea);    // 2 * den * X on the edge; column = X / 2
         const int c = LOWER ? (num >= 0 ? (num + twoden - 1) / twoden : -((-num) / twoden))      // ceil
                             : (num >= 0 ? num / twoden : -((-num + twoden - 1) / twoden));       // floor
-        bound[2 * r + (LOWER ? 0 : 1)] = c;
+        bound[2 * r + (LOWER ? 0 : 1)] = (hull_t)c;
     }
 }
 __global__ __launch_bounds__(128) void k_convex(int n_saved, const int32_t *__restrict__ geo, const long long *__restrict__ row_off,
@@ -1490,12 +1491,12 @@ __global__ __launch_bounds__(128) void k_convex(int n_saved, const int32_t *__re
     const int h = geo[8 * (size_t)s + 4];
     if (h <= hlo || h > hhi) return;                        // another size class
     const int np = 2 * h + 1;
-    int *fl = (int *)hull_smem;                             // first / last column per row; later the two column bounds
+    hull_t *fl = (hull_t *)hull_smem;                       // first / last column per row (last = -1: empty row); later the two column bounds
     const int npm = 2 * hhi + 1;
-    int *pvl = fl + 2 * hhi, *pvu = pvl + npm, *nxl = pvu + npm, *prl = nxl + npm, *nxu = prl + npm, *pru = nxu + npm;
+    hull_t *pvl = fl + 2 * hhi, *pvu = pvl + npm, *nxl = pvu + npm, *prl = nxl + npm, *nxu = prl + npm, *pru = nxu + npm;
     long long *q = sums + (size_t)s * PSEG_NSUMS;
     const int32_t *re = rowext + 2 * row_off[s];
-    for (int i = threadIdx.x; i < 2 * h; i += 128) fl[i] = re[i];
+    for (int i = threadIdx.x; i < 2 * h; i += 128) { const int v = re[i]; fl[i] = (hull_t)(v > 32767 ? 32767 : v); }   // (first = INT_MAX in empty rows)
     __syncthreads();
     // rows without a set pixel (possible between the components of a dense mask, pseg_regionprops) give no hull points:
     // their profile values lie beyond every real column, small enough for the 32-bit cross products
@@ -1512,7 +1513,7 @@ __global__ __launch_bounds__(128) void k_convex(int n_saved, const int32_t *__re
             const int la = lo_of(r - 1), lb = lo_of(r), ua = hi_of(r - 1), ub = hi_of(r);
             l = la < lb ? la : lb; u = ua > ub ? ua : ub;
         }
-        pvl[i] = l; pvu[i] = u;
+        pvl[i] = (hull_t)l; pvu[i] = (hull_t)u;
     }
     __syncthreads();
     if (threadIdx.x < 64) hull_chain<true>(pvl, np, nxl, prl, fl, h, threadIdx.x);
@@ -1987,7 +1988,7 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
         // (a tallest object of up to 448 rows = 25 KB still leaves 6 blocks per CU: one launch, one kernel latency less)
         const int hsmall = hmax <= 448 ? hmax : 256;
         const size_t lds_small = (size_t)hsmall * HULL_LDS_PER_ROW + 64, lds_big = (size_t)hmax * HULL_LDS_PER_ROW + 64;
-        if (lds_big > 150 * 1024) return fail(ctx, PSEG_ERR_CAPACITY, "saved object too tall for the convex-hull kernel (limit 2700 rows)");
+        if (hmax > 2700) return fail(ctx, PSEG_ERR_CAPACITY, "saved object too tall for the convex-hull kernel (limit 2700 rows)");
         if (lds_big > 48 * 1024)
             HIPCHK(hipFuncSetAttribute((const void *)k_convex, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big));
         hipLaunchKernelGGL(k_convex, dim3(n_saved), dim3(128), lds_small, st, n_saved, (const int32_t *)geo,
@@ -2270,7 +2271,7 @@ extern "C" int pseg_regionprops(pseg_ctx *ctx, const uint8_t *mask, const uint8_
     if (!mask || !img || !props || h < 1 || w < 1 || w > 8192 || h > 65535 || stride < w) return fail(ctx, PSEG_ERR_ARG, "bad window");
     HIPCHK(hipSetDevice(ctx->device));
     const size_t lds = (size_t)h * HULL_LDS_PER_ROW + 64;
-    if (lds > 150 * 1024) return fail(ctx, PSEG_ERR_CAPACITY, "window too tall for the convex-hull kernel (limit 2700 rows)");
+    if (h > 2700) return fail(ctx, PSEG_ERR_CAPACITY, "window too tall for the convex-hull kernel (limit 2700 rows)");
     hipStream_t st = ctx->stream;
     const int rpb = crop_rows_per_band(w), nbands = (h + rpb - 1) / rpb;
     // small tables: geo[8] | crop_off[2] | band_off[2] | row_off[2] (long long) | band_obj[nbands] | sums[24] | rowext[2h]
