@@ -188,6 +188,7 @@ def main():
     else:   # sparse groups: their share of the path's compulsory bytes is the object payload only
         launch_bytes = (stats["crop_bytes"] * 3 + stats["rows"] * 44 * 8) / max(args.steps, 1) * bpc
     achieved = launch_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    obj_bytes = (stats["crop_bytes"] * 3 + stats["rows"] * 44 * 8) / max(args.steps * BATCH, 1)     # rank 0's batches
     out = {
         "metric": "frames/sec (2560x2560 uint8), hot path bg_correction+detection",
         "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -202,6 +203,10 @@ def main():
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "avg_launch_ms": round(dom_ms, 4), "bytes_per_launch": int(launch_bytes)},
         "path": {"bytes_per_frame": PATH_BYTES_PER_FRAME if not args.no_labels else 2 * P,
+                 # compulsory bytes = the frame terms + the measured object payload (three crop planes, 44 x 8 B per row)
+                 "object_bytes_per_frame": round(obj_bytes, 1),
+                 "frac_of_hbm_peak_per_gpu_with_objects": round(fps / world * ((PATH_BYTES_PER_FRAME if not args.no_labels else 2 * P) + obj_bytes)
+                                                                / (HBM_PEAK_GBS * 1e9), 4),
                  "frac_of_hbm_peak_per_gpu": round(fps / world * (PATH_BYTES_PER_FRAME if not args.no_labels else 2 * P) / (HBM_PEAK_GBS * 1e9), 4),
                  "contexts": ns, "table_gather_ms_per_step_rank0": round(stats["gather_s"] / args.steps * 1e3, 3) if world > 1 else None,
                  "batches_per_call": bpc,
