@@ -4,8 +4,8 @@
 // runs per row, union-find over runs (8-connected foreground, 4-connected background incl. the
 // zero padding the reference's findContours assumes), the enclosure tree (external component ->
 // hole -> nested component ...), and per-object integer accumulators.  The bodies are plain
-// functions of a thread index so that the HIP kernels in piscoseg.hip are one-line wrappers and
-// the test-only serial emulator (tests/emu) can run the identical logic on a CPU.
+// functions of a thread index so that the HIP kernels in piscoseg.hip are one-line wrappers (the
+// host versions of the atomics below let the same bodies be compiled and stepped on a CPU).
 //
 // Reference semantics restated:
 //   cv.findContours(RETR_EXTERNAL)      detection.py:204  -> external components = components
@@ -70,8 +70,8 @@ PSEG_HD int seg_b0(const SegState &S, int f) { return (int)S.framebase[f] + f * 
 PSEG_HD int run_xs(const SegState &S, int r) { return (int)(S.run_x[r] & 0xffffu); }
 PSEG_HD int run_xe(const SegState &S, int r) { return (int)(S.run_x[r] >> 16); }
 
-// Runs are extracted by one wave per row (k_count_runs / k_fill_runs in piscoseg.hip): starts = v & ~((v << 1) | carry),
-// an in-wave prefix sum gives every word its first run index.
+// Runs are extracted in two passes over the plane (k_runs_quad / k_runs in piscoseg.hip, count then fill): starts =
+// v & ~((v << 1) | carry) per 64-bit word, a scan of the per-row counts gives every row its first run index.
 
 // ---- union-find (link the larger root under the smaller one) -------------------------------
 PSEG_HD int uf_find(const int32_t *parent, int a)
