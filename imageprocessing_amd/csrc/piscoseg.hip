@@ -751,6 +751,13 @@ __global__ __launch_bounds__(256) void k_runs_quad(SegState S, int nrows, int wp
 __global__ void k_init(SegState S, int nfg, int nt) { size_t g = GTID; if (g < (size_t)nt) init_body(S, (int)g, nfg); }
 __global__ void k_fg_union(SegState S, int nfg, int bandh) { size_t g = GTID; if (g < (size_t)nfg) fg_union_body(S, (int)g, bandh); }
 __global__ void k_bg_union(SegState S, int nfg, int nt, int bandh) { size_t g = GTID; if (g < (size_t)nt) bg_union_body(S, (int)g, nfg, bandh); }
+// both union passes in one launch (two independent union-find structures)
+__global__ void k_unions(SegState S, int nfg, int nt, int bandh)
+{
+    size_t g = GTID;
+    if (g < (size_t)nfg) fg_union_body(S, (int)g, bandh);
+    if (g < (size_t)nt) bg_union_body(S, (int)g, nfg, bandh);
+}
 
 // ---- band-local labelling in LDS ----------------------------------------------------------------------------------
 // Block = one band of BAND_H rows of one frame.  The band's runs and gaps are united with a union-find that lives in
@@ -1898,12 +1905,10 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
     if (bandmax <= BAND_CAP && !ctx->no_bands) {
         // bands of BAND_H rows are labelled in LDS; the global kernels only unite across the band boundaries
         hipLaunchKernelGGL(k_band_label, dim3((H + BAND_H - 1) / BAND_H, n), dim3(256), 0, st, S);
-        if (nfg > 0) hipLaunchKernelGGL(k_fg_union, dim3(nblocks(nfg)), dim3(256), 0, st, S, nfg, BAND_H);
-        hipLaunchKernelGGL(k_bg_union, dim3(nblocks(nbg)), dim3(256), 0, st, S, nfg, nbg, BAND_H);
+        hipLaunchKernelGGL(k_unions, dim3(nblocks(nbg)), dim3(256), 0, st, S, nfg, nbg, BAND_H);
     } else {
         hipLaunchKernelGGL(k_init, dim3(nblocks(nbg)), dim3(256), 0, st, S, nfg, nbg);
-        if (nfg > 0) hipLaunchKernelGGL(k_fg_union, dim3(nblocks(nfg)), dim3(256), 0, st, S, nfg, 0);
-        hipLaunchKernelGGL(k_bg_union, dim3(nblocks(nbg)), dim3(256), 0, st, S, nfg, nbg, 0);
+        hipLaunchKernelGGL(k_unions, dim3(nblocks(nbg)), dim3(256), 0, st, S, nfg, nbg, 0);
     }
     hipLaunchKernelGGL(k_flatten, dim3(nblocks(nbg)), dim3(256), 0, st, S, nfg, nbg);
     if (nfg > 0) {
