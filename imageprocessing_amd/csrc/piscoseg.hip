@@ -749,8 +749,6 @@ __global__ __launch_bounds__(256) void k_runs_quad(SegState S, int nrows, int wp
     }
 }
 __global__ void k_init(SegState S, int nfg, int nt) { size_t g = GTID; if (g < (size_t)nt) init_body(S, (int)g, nfg); }
-__global__ void k_fg_union(SegState S, int nfg, int bandh) { size_t g = GTID; if (g < (size_t)nfg) fg_union_body(S, (int)g, bandh); }
-__global__ void k_bg_union(SegState S, int nfg, int nt, int bandh) { size_t g = GTID; if (g < (size_t)nt) bg_union_body(S, (int)g, nfg, bandh); }
 // both union passes in one launch (two independent union-find structures)
 __global__ void k_unions(SegState S, int nfg, int nt, int bandh)
 {
@@ -762,7 +760,7 @@ __global__ void k_unions(SegState S, int nfg, int nt, int bandh)
 // ---- band-local labelling in LDS ----------------------------------------------------------------------------------
 // Block = one band of BAND_H rows of one frame.  The band's runs and gaps are united with a union-find that lives in
 // LDS (same rules as fg_union_body / bg_union_elem, local indices), flattened, and written to the global parent arrays
-// as global indices; k_fg_union / k_bg_union then only unite across the band boundaries and k_flatten finishes.  The
+// as global indices; k_unions then only unites across the band boundaries and k_flatten_resolve finishes.  The
 // frame-connected background (smallest background index of the frame, seg_b0) is the virtual node -1 here.  Also does
 // the work of k_init for the band.  Used when no band of the batch has more than BAND_CAP runs (k_scan_rows reports
 // the maximum); otherwise the host takes the global path.
@@ -854,13 +852,25 @@ __global__ __launch_bounds__(256) void k_band_label(SegState S)
         S.bg_parent[Bb + i] = rt < 0 ? B0g : Bb + rt;
     }
 }
-__global__ void k_flatten(SegState S, int nfg, int nbg)
+// flatten + enclosure tree in one launch: every parent is followed to its root on the fly (the parents other threads
+// flatten meanwhile are only ever replaced by one of their ancestors, so a chain stays a chain to the same root)
+__global__ void k_flatten_resolve(SegState S, int nfg, int nbg)
 {
     size_t g = GTID;
-    if (g < (size_t)nfg) flatten_body(S.fg_parent, (int)g);
-    if (g < (size_t)nbg) flatten_body(S.bg_parent, (int)g);
+    if (g < (size_t)nbg) S.bg_parent[g] = uf_find(S.bg_parent, (int)g);
+    if (g >= (size_t)nfg) return;
+    const int r = (int)g;
+    const int root = uf_find(S.fg_parent, r);
+    int R = root;
+    for (int guard = 0; guard < 65536; guard++) {
+        const int y = (int)(S.run_fy[R] & 0xffffu), f = (int)(S.run_fy[R] >> 16);
+        const int hb = uf_find(S.bg_parent, R + f * S.H + y);   // background around R's raster-first pixel
+        if (hb == seg_b0(S, f)) break;                       // frame-connected: R is external
+        R = uf_find(S.fg_parent, S.bg_left[hb]);             // component that owns the hole
+    }
+    S.fg_parent[r] = root;
+    S.ext[r] = R;
 }
-__global__ void k_resolve_ext(SegState S, int nfg) { size_t g = GTID; if (g < (size_t)nfg) resolve_ext_body(S, (int)g); }
 // bounding boxes: the 256 runs of a block are combined per object in an LDS hash table first, so that
 // only one set of global atomics is issued per (block, object)
 __global__ __launch_bounds__(256) void k_bbox(SegState S, int nfg)
@@ -1910,9 +1920,8 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
         hipLaunchKernelGGL(k_init, dim3(nblocks(nbg)), dim3(256), 0, st, S, nfg, nbg);
         hipLaunchKernelGGL(k_unions, dim3(nblocks(nbg)), dim3(256), 0, st, S, nfg, nbg, 0);
     }
-    hipLaunchKernelGGL(k_flatten, dim3(nblocks(nbg)), dim3(256), 0, st, S, nfg, nbg);
+    hipLaunchKernelGGL(k_flatten_resolve, dim3(nblocks(nbg)), dim3(256), 0, st, S, nfg, nbg);
     if (nfg > 0) {
-        hipLaunchKernelGGL(k_resolve_ext, dim3(nblocks(nfg)), dim3(256), 0, st, S, nfg);
         hipLaunchKernelGGL(k_bbox, dim3(nblocks(nfg)), dim3(256), 0, st, S, nfg);
         hipLaunchKernelGGL(k_area, dim3(nblocks(nfg)), dim3(256), 0, st, S, nfg);
     }

@@ -176,20 +176,10 @@ PSEG_HD void bg_union_body(const SegState &S, int t, int nfg, int bandh = 0)
     }
 }
 
-PSEG_HD void flatten_body(int32_t *parent, int i) { parent[i] = uf_find(parent, i); }
-
-// ---- 5. enclosure tree: external ancestor of every run ---------------------------------------
-PSEG_HD void resolve_ext_body(const SegState &S, int r)
-{
-    int R = S.fg_parent[r];
-    for (int guard = 0; guard < 65536; guard++) {
-        int y = (int)(S.run_fy[R] & 0xffffu), f = (int)(S.run_fy[R] >> 16);
-        int hb = S.bg_parent[R + f * S.H + y];           // background around R's raster-first pixel
-        if (hb == seg_b0(S, f)) break;                   // frame-connected: R is external
-        R = S.fg_parent[S.bg_left[hb]];                  // component that owns the hole
-    }
-    S.ext[r] = R;
-}
+// ---- 5. enclosure tree: external ancestor of every run (k_flatten_resolve in piscoseg.hip) -----
+// From a component's root run R: the background element around R's raster-first pixel is either the
+// frame-connected background (R is external) or a hole, whose owner is the component of the run left of the
+// hole's root gap; repeat from there.
 // object id of a background element: -1 = outside every object
 PSEG_HD int bg_gid(const SegState &S, int f, int b)
 {
