@@ -1092,7 +1092,9 @@ __global__ __launch_bounds__(256) void k_label_fill(SegState S, const int32_t *_
 #define CROP_TPR 4                   // threads that share the runs of one row while the mask is painted (64 rows at a time;
                                      // 16 / 8 / 2 threads per row: 0.384 / 0.351 / 0.338 ms for the crop group against 0.334 ms)
 #endif
+#ifndef CROP_LDS_WORDS
 #define CROP_LDS_WORDS 1536          // mask words of a band + 2 halo rows on each side (frames up to 8192 px wide)
+#endif
 __host__ __device__ inline int crop_rows_per_band(int w)
 {
     int r = CROP_BAND / w;
