@@ -898,7 +898,31 @@ __global__ __launch_bounds__(256) void k_bbox(SegState S, int nfg)
     for (int i = threadIdx.x; i < 512; i += 256)
         if (keys[i] >= 0) bbox_flush(S, keys[i], vminx[i], vmaxx[i], vmaxy[i]);
 }
-__global__ void k_area(SegState S, int nfg) { size_t g = GTID; if (g < (size_t)nfg) area_body(S, (int)g); }
+// contour areas: the contributions of a block's 256 runs are summed per object in an LDS hash table first (a large
+// object receives one contribution per row and span: hundreds of atomics on one word otherwise)
+__global__ __launch_bounds__(256) void k_area(SegState S, int nfg)
+{
+    __shared__ int keys[512], vsum[512];
+    for (int i = threadIdx.x; i < 512; i += 256) { keys[i] = -1; vsum[i] = 0; }
+    __syncthreads();
+    size_t g = GTID;
+    if (g < (size_t)nfg) {
+        int E;
+        const int add = area_contrib(S, (int)g, &E);
+        if (add) {
+            unsigned h = ((unsigned)E * 2654435761u) >> 23;   // 9 bits
+            for (;;) {
+                int old = atomicCAS(&keys[h], -1, E);
+                if (old == -1 || old == E) break;
+                h = (h + 1) & 511;
+            }
+            atomicAdd(&vsum[h], add);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 512; i += 256)
+        if (keys[i] >= 0) atomicAdd(&S.area2[keys[i]], vsum[i]);
+}
 
 // exclusive scan of rowcnt inside each frame (block per frame); ftot[f] = runs in frame f
 __global__ __launch_bounds__(256) void k_scan_rows(SegState S, uint32_t *ftot, uint32_t *bandmax)

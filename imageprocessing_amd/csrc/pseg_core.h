@@ -204,14 +204,16 @@ PSEG_HD void bbox_flush(const SegState &S, int E, int xs, int xe, int y)
 // of the same object on either side).  Thread per run: the run that begins a span walks to the span's end, finds the
 // spans of the same object in the next row that overlap it and adds, per pair [a,b] x [c,d],
 //   2 * #(columns x with x, x+1 in both)  +  #(2x2 quads with exactly three pixels set)   to area2[object].
-PSEG_HD void area_body(const SegState &S, int r)
+// Returns the contribution of run r (0 for runs that do not begin a span) and its object in *obj.
+PSEG_HD int area_contrib(const SegState &S, int r, int *obj)
 {
     const int id = S.ext[r];
+    *obj = id;
     const int y = (int)(S.run_fy[r] & 0xffffu), f = (int)(S.run_fy[r] >> 16);
-    if (y + 1 >= S.H) return;
+    if (y + 1 >= S.H) return 0;
     const int rs = seg_rowstart(S, f, y), re = seg_rowstart(S, f, y + 1), ne = re + seg_rowcount(S, f, y + 1);
-    if (re == ne) return;                                // the next row has no runs
-    if (r > rs && S.gapl[r] == id) return;               // not the first run of its span
+    if (re == ne) return 0;                              // the next row has no runs
+    if (r > rs && S.gapl[r] == id) return 0;             // not the first run of its span
     const int a = run_xs(S, r);
     int e = r;
     while (e + 1 < re && S.gapl[e + 1] == id) e++;
@@ -234,6 +236,12 @@ PSEG_HD void area_body(const SegState &S, int r)
         }
         q = qe + 1;
     }
+    return add;
+}
+PSEG_HD void area_body(const SegState &S, int r)
+{
+    int id;
+    const int add = area_contrib(S, r, &id);
     if (add) PSEG_ATOMIC_ADD(&S.area2[id], add);
 }
 
