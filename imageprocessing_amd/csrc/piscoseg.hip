@@ -927,26 +927,23 @@ __global__ __launch_bounds__(256) void k_area(SegState S, int nfg)
 // exclusive scan of rowcnt inside each frame (block per frame); ftot[f] = runs in frame f
 __global__ __launch_bounds__(256) void k_scan_rows(SegState S, uint32_t *ftot, uint32_t *bandmax)
 {
-    __shared__ uint32_t sh[256];
+    __shared__ uint32_t wtot[4];
     __shared__ uint32_t carry;
-    int f = blockIdx.x, H = S.H;
+    const int f = blockIdx.x, H = S.H, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
     for (int base = 0; base < H; base += 256) {
-        int y = base + threadIdx.x;
-        uint32_t v = y < H ? S.rowcnt[(size_t)f * H + y] : 0;
-        sh[threadIdx.x] = v;
+        const int y = base + threadIdx.x;
+        const uint32_t v = y < H ? S.rowcnt[(size_t)f * H + y] : 0;
+        uint32_t incl = v;                                   // inclusive scan inside the wave, then across the four waves
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+        if (lane == 63) wtot[wv] = incl;
         __syncthreads();
-        for (int o = 1; o < 256; o <<= 1) {
-            uint32_t t = threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
-            __syncthreads();
-            sh[threadIdx.x] += t;
-            __syncthreads();
-        }
-        uint32_t incl = sh[threadIdx.x], c0 = carry;
-        if (y < H) S.rowoff[(size_t)f * (H + 1) + y] = c0 + incl - v;
+        uint32_t pre = carry;
+        for (int w = 0; w < wv; w++) pre += wtot[w];
+        if (y < H) S.rowoff[(size_t)f * (H + 1) + y] = pre + incl - v;
         __syncthreads();
-        if (threadIdx.x == 255) carry = c0 + incl;
+        if (threadIdx.x == 255) carry = pre + incl;
         __syncthreads();
     }
     if (threadIdx.x == 0) { S.rowoff[(size_t)f * (H + 1) + H] = carry; ftot[f] = carry; }
@@ -959,7 +956,12 @@ __global__ __launch_bounds__(256) void k_scan_rows(SegState S, uint32_t *ftot, u
         bm = c > bm ? c : bm;
     }
     for (int o = 32; o > 0; o >>= 1) { uint32_t t = __shfl_xor(bm, o, 64); bm = t > bm ? t : bm; }
-    if ((threadIdx.x & 63) == 0 && bm) atomicMax(bandmax, bm);
+    if (lane == 0) wtot[wv] = bm;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; w++) bm = wtot[w] > bm ? wtot[w] : bm;
+        if (bm > *(volatile uint32_t *)bandmax) atomicMax(bandmax, bm);      // (a stale read only costs a redundant atomic)
+    }
 }
 
 // exclusive scan over the frames by one block: out[0..F] (strided input / output)
