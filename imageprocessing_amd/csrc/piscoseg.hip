@@ -1205,6 +1205,14 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 //  phase 2: crops (detection.py:243-247) and the sums, combined across bands with integer atomics (exact).
 // sums[s*PSEG_NSUMS + k]: 0 N, 1 sum r, 2 sum c, 3 sum r^2, 4 sum c^2, 5 sum r*c, 6 min I, 7 max I, 8 sum I,
 //   9 filled area, 10..12 perimeter code counts (weight 1, sqrt2, (1+sqrt2)/2), 13 euler, 14 convex area
+// p / d and p % d for small non-negative p (< 2^22) with the reciprocal in single precision and one correction step: the
+// integer division of the compiler is some 25 instructions, several of them quarter-rate 32-bit multiplies
+__device__ __forceinline__ void divmod_small(int p, int d, float rcp, int &q, int &r)
+{
+    q = (int)((float)p * rcp);
+    r = p - (int)__umul24((uint32_t)q, (uint32_t)d);
+    if (r < 0) { q--; r += d; } else if (r >= d) { q++; r -= d; }
+}
 template <bool DENSE>
 __global__ __launch_bounds__(CROP_THREADS) void k_crops_sums(SegState S, int n_saved, const int32_t *__restrict__ geo,
                                                     const long long *__restrict__ crop_off, const long long *__restrict__ band_off,
@@ -1224,6 +1232,7 @@ __global__ __launch_bounds__(CROP_THREADS) void k_crops_sums(SegState S, int n_s
     const int rpb = crop_rows_per_band(w);
     const int r0 = (int)(bid - band_off[s]) * rpb, r1 = (r0 + rpb < h) ? r0 + rpb : h;
     const int nrows = r1 - r0;
+    const float rcp_wpr = 1.0f / (float)wpr, rcp_wpr1 = 1.0f / (float)(wpr + 1);
     for (int wi = threadIdx.x; wi < (nrows + 4) * wpr; wi += CROP_THREADS) mbuf[wi] = 0;
     if (threadIdx.x < 32) acc[threadIdx.x] = threadIdx.x == 15 ? 255u : 0u;    // acc[15] = running minimum
     __syncthreads();
@@ -1271,8 +1280,9 @@ __global__ __launch_bounds__(CROP_THREADS) void k_crops_sums(SegState S, int n_s
     // border = mask minus its erosion by the 4-neighbour cross, zero outside the window
     // (skimage perimeter(image, 4): binary_erosion(..., border_value=0), _regionprops_utils.py:225-231)
     for (int wi = threadIdx.x; wi < (nrows + 2) * wpr; wi += CROP_THREADS) {
-        int yl = wi / wpr, wx = wi - yl * wpr;             // row r0-1+yl  ->  mbuf row yl+1
-        const uint32_t *m = mbuf + (yl + 1) * wpr;
+        int yl, wx;                                        // row r0-1+yl  ->  mbuf row yl+1
+        divmod_small(wi, wpr, rcp_wpr, yl, wx);
+        const uint32_t *m = mbuf + __umul24((uint32_t)(yl + 1), (uint32_t)wpr);
         uint32_t c = m[wx], up = m[wx - wpr], dn = m[wx + wpr];
         uint32_t lf = (c << 1) | (wx > 0 ? m[wx - 1] >> 31 : 0u);
         uint32_t rt = (c >> 1) | (wx + 1 < wpr ? m[wx + 1] << 31 : 0u);
@@ -1296,17 +1306,19 @@ __global__ __launch_bounds__(CROP_THREADS) void k_crops_sums(SegState S, int n_s
         const float rcp = 1.0f / (float)cpr;
 #pragma unroll CROP_UNROLL
         for (int p = threadIdx.x; p < nitem; p += CROP_THREADS) {
+            // (products of values below 2^24 go through v_mul_u32_u24: the full 32-bit multiply runs at a quarter of the rate)
             int yl = (int)((float)p * rcp);               // p / cpr, corrected below (p < 2^24)
-            int c = p - yl * cpr;
+            int c = p - (int)__umul24((uint32_t)yl, (uint32_t)cpr);
             if (c < 0) { yl--; c += cpr; } else if (c >= cpr) { yl++; c -= cpr; }
             int xx = 4 * c;
             const int over = xx - (w - 4);                // > 0 only for the last chunk of a row when w % 4 != 0
             uint32_t keep = 0xffffffffu;
             if (over > 0) { xx = w - 4; keep <<= 8 * over; }
-            const uint32_t *mw = mb + yl * wpr + (xx >> 5);
+            const uint32_t *mw = mb + __umul24((uint32_t)yl, (uint32_t)wpr) + (xx >> 5);
             const uint32_t bits4 = __builtin_amdgcn_alignbit(mw[1], mw[0], (uint32_t)(xx & 31)) & 0xfu;
-            const uint32_t so = (uint32_t)yl * (uint32_t)S.W + (uint32_t)xx, qo = (uint32_t)yl * (uint32_t)w + (uint32_t)xx;
-            const uint32_t m4 = ((bits4 * 0x00204081u) & 0x01010101u) * 255u;     // bit k -> byte k
+            const uint32_t so = __umul24((uint32_t)yl, (uint32_t)S.W) + (uint32_t)xx, qo = __umul24((uint32_t)yl, (uint32_t)w) + (uint32_t)xx;
+            const uint32_t m1 = __umul24(bits4, 0x00204081u) & 0x01010101u;       // bit k -> bit 0 of byte k
+            const uint32_t m4 = (m1 << 8) - m1;                                   // ... -> byte k = 255
             uint32_t cv4, rv4;
             __builtin_memcpy(&cv4, sb + so, 4);
             if (same) rv4 = cv4; else __builtin_memcpy(&rv4, rb + so, 4);
@@ -1345,7 +1357,9 @@ __global__ __launch_bounds__(CROP_THREADS) void k_crops_sums(SegState S, int n_s
     uint32_t mo[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // n, wx n, wx^2 n, sk, wx sk, sk2, yl n, yl^2 n, yl wx n, yl sk
     uint32_t pc1 = 0, pc2 = 0, pc3 = 0;
     for (int wi = threadIdx.x; wi < nrows * wpr; wi += CROP_THREADS) {
-        const uint32_t yl = (uint32_t)(wi / wpr), wx = (uint32_t)wi - yl * (uint32_t)wpr;
+        int yl_, wx_;
+        divmod_small(wi, wpr, rcp_wpr, yl_, wx_);
+        const uint32_t yl = (uint32_t)yl_, wx = (uint32_t)wx_;
         const uint32_t v = mb[wi];
         if (v) {
             const uint32_t M[5] = {0xaaaaaaaau, 0xccccccccu, 0xf0f0f0f0u, 0xff00ff00u, 0xffff0000u};
@@ -1357,10 +1371,12 @@ __global__ __launch_bounds__(CROP_THREADS) void k_crops_sums(SegState S, int n_s
 #pragma unroll
                 for (int c2 = b2 + 1; c2 < 5; c2++) sk2 += (uint32_t)__popc(v & M[b2] & M[c2]) << (b2 + c2 + 1);
             }
-            mo[0] += n1; mo[1] += wx * n1; mo[2] += wx * wx * n1; mo[3] += sk; mo[4] += wx * sk; mo[5] += sk2;
-            mo[6] += yl * n1; mo[7] += yl * yl * n1; mo[8] += yl * wx * n1; mo[9] += yl * sk;
+            // (all factors are far below 2^24: 24-bit multiplies)
+            const uint32_t wn = __umul24(wx, n1), yn = __umul24(yl, n1);
+            mo[0] += n1; mo[1] += wn; mo[2] += __umul24(wx, wn); mo[3] += sk; mo[4] += __umul24(wx, sk); mo[5] += sk2;
+            mo[6] += yn; mo[7] += __umul24(yl, yn); mo[8] += __umul24(yl, wn); mo[9] += __umul24(yl, sk);
         }
-        const uint32_t *bc = bd + (yl + 1) * wpr + wx;     // border row r0+yl
+        const uint32_t *bc = bd + __umul24(yl + 1, (uint32_t)wpr) + wx;     // border row r0+yl
         const uint32_t C = bc[0];
         if (C) {
             const bool hl = wx > 0, hr = wx + 1 < (uint32_t)wpr;
@@ -1390,8 +1406,9 @@ __global__ __launch_bounds__(CROP_THREADS) void k_crops_sums(SegState S, int n_s
     {
         const int ylast = (r1 == h) ? nrows + 1 : nrows;   // the last band also owns the quads below the window
         for (int wi = threadIdx.x; wi < ylast * (wpr + 1); wi += CROP_THREADS) {
-            int yl = wi / (wpr + 1), wx = wi - yl * (wpr + 1);
-            const uint32_t *B = mbuf + (yl + 2) * wpr, *T = B - wpr;     // bottom row r0+yl, top row r0+yl-1
+            int yl, wx;
+            divmod_small(wi, wpr + 1, rcp_wpr1, yl, wx);
+            const uint32_t *B = mbuf + __umul24((uint32_t)(yl + 2), (uint32_t)wpr), *T = B - wpr;     // bottom row r0+yl, top row r0+yl-1
             uint32_t tr = wx < wpr ? T[wx] : 0u, br = wx < wpr ? B[wx] : 0u;
             uint32_t tl = (tr << 1) | (wx > 0 ? T[wx - 1] >> 31 : 0u), bl = (br << 1) | (wx > 0 ? B[wx - 1] >> 31 : 0u);
             eul += __popc(tl & ~tr & ~bl & ~br) - __popc(~tl & tr & bl & ~br) - __popc(tl & tr & bl & ~br);
