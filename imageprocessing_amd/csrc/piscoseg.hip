@@ -1128,7 +1128,7 @@ __host__ __device__ inline int crop_rows_per_band(int w)
     return r < 1 ? 1 : r;
 }
 __global__ void k_saved_geo(const uint32_t *n_saved_p, const int32_t *saved_row, RowsDev R, int32_t *geo, unsigned long long *sz,
-                            long long *totals)
+                            long long *)
 {
     size_t g = GTID;
     if (g >= (size_t)*n_saved_p) return;
@@ -1140,7 +1140,6 @@ __global__ void k_saved_geo(const uint32_t *n_saved_p, const int32_t *saved_row,
     sz[3 * g] = (unsigned long long)w * h;
     sz[3 * g + 1] = (unsigned long long)h;                 // rows: offset of the object's per-row extremes
     sz[3 * g + 2] = (unsigned long long)((h + rpb - 1) / rpb);
-    if (h > totals[3]) atomicMax(&totals[3], (long long)h);    // tallest saved object: LDS size of k_convex
 }
 // exclusive scans of the three size columns by one block of 1024 threads; out[k][0..n].  A thread takes 8 consecutive
 // objects (one pass of wave / block scans per 8192 objects)
@@ -1154,12 +1153,15 @@ __global__ __launch_bounds__(1024) void k_scan_sizes(const unsigned long long *s
     if (threadIdx.x < 3) carry[threadIdx.x] = 0;
     __syncthreads();
     long long *outp[3] = {crop_off, bits_off, band_off};
+    unsigned long long hmax = 0;                             // tallest saved object (LDS size of k_convex): totals[3]
     for (int base = 0; base < n; base += 1024 * SCAN_IPT) {
         const int i0 = base + threadIdx.x * SCAN_IPT;
         unsigned long long v[SCAN_IPT][3], tot[3] = {0, 0, 0}, inc[3];
 #pragma unroll
-        for (int j = 0; j < SCAN_IPT; j++)
+        for (int j = 0; j < SCAN_IPT; j++) {
             for (int k = 0; k < 3; k++) { v[j][k] = (i0 + j < n) ? sz[3 * (size_t)(i0 + j) + k] : 0; tot[k] += v[j][k]; }
+            hmax = v[j][1] > hmax ? v[j][1] : hmax;          // column 1 = rows of the object
+        }
         for (int k = 0; k < 3; k++) {                        // inclusive scan of the thread totals inside the wave
             unsigned long long x = tot[k];
             for (int o = 1; o < 64; o <<= 1) { unsigned long long t = __shfl_up(x, o, 64); if (lane >= o) x += t; }
@@ -1179,6 +1181,14 @@ __global__ __launch_bounds__(1024) void k_scan_sizes(const unsigned long long *s
         __syncthreads();
     }
     if (threadIdx.x < 3) { outp[threadIdx.x][n] = (long long)carry[threadIdx.x]; totals[threadIdx.x] = (long long)carry[threadIdx.x]; }
+    for (int o = 32; o > 0; o >>= 1) { const unsigned long long t = __shfl_xor(hmax, o, 64); hmax = t > hmax ? t : hmax; }
+    __syncthreads();
+    if (lane == 0) wtot[wv][0] = hmax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; w++) hmax = wtot[w][0] > hmax ? wtot[w][0] : hmax;
+        totals[3] = (long long)hmax;
+    }
 }
 
 // band -> saved object (one wave per object), so that a band's block starts with one load instead of a binary search
