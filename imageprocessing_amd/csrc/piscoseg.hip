@@ -75,6 +75,8 @@ struct pseg_ctx {
     bool early_release = true;    // hand the turn on behind the label fill instead of behind the last kernel (PSEG_EARLY_RELEASE=0)
     struct GpuTurn *turn = nullptr;
     int bg_chunks = 1;            // time chunks of the streaming background kernel (PSEG_BG_CHUNKS)
+    int bg_resident = 0;          // blocks of the streaming background kernel the device holds at once (0: no tail split)
+    int bounds_tailk = -1;
     bool force_generic = false;   // PSEG_BG_GENERIC=1: use the 12x-read reference kernel (debug / cross-check)
     bool no_bands = false;        // PSEG_NO_BANDS=1: label with the global union-find only (the path of very dense frames)
     // host results
@@ -421,13 +423,23 @@ template <bool PAD>
 __global__ __launch_bounds__(256, 4) void k_bg_stream(const uint8_t *__restrict__ frames, size_t P, uint8_t *__restrict__ cleaned,
                                                       const uint8_t *__restrict__ mask, int thr, uint8_t *__restrict__ bits8,
                                                       uint4 *__restrict__ partials, const int *__restrict__ bounds,
-                                                      uint8_t *__restrict__ trash, uint32_t *__restrict__ maskpart)
+                                                      uint8_t *__restrict__ trash, uint32_t *__restrict__ maskpart,
+                                                      int nfull, int tailk)
 {
     __shared__ uint2 lds[BG_SLOTS * 256];
-    size_t strip = (size_t)blockIdx.x * 256 + threadIdx.x;
+    // strips [0, nfull) walk their whole chunk; each strip behind them is shared by tailk blocks, which walk the tail bounds
+    // (stored behind the chunk tables; tailk > 1 only with one chunk) -- see run_bg
+    int col = blockIdx.x, bi = blockIdx.y;
+    if (tailk > 1 && col >= nfull) {
+        const int t = col - nfull;
+        col = nfull + t / tailk;
+        bi = 2 * gridDim.y + 1 + (t - (col - nfull) * tailk);
+    }
+    const int ncols = nfull + (gridDim.x - nfull) / tailk;
+    size_t strip = (size_t)col * 256 + threadIdx.x;
     const bool act = strip * 8 < P;                         // padding lanes stay in the wave (DPP sums), load strip 0, store nothing
     if (!act) strip = 0;
-    const int a = bounds[blockIdx.y], b = bounds[blockIdx.y + 1];
+    const int a = bounds[bi], b = bounds[bi + 1];
     const int n = bounds[gridDim.y + 1 + blockIdx.y];        // end of the reference batch this chunk belongs to
     const int kend = (b == n) ? n - 1 : b + 10;
     BgEmit E;
@@ -443,8 +455,8 @@ __global__ __launch_bounds__(256, 4) void k_bg_stream(const uint8_t *__restrict_
     E.kadd = (uint32_t)(t1 <= 128 ? 128 - t1 : 256 - (t1 > 255 ? 255 : t1)) * 0x01010101u;
     E.lowm = t1 <= 128 ? 0xffffffffu : 0u;
     E.m80 = thr_ok ? make_uint2(E.inm.x & 0x80808080u, E.inm.y & 0x80808080u) : make_uint2(0u, 0u);
-    E.nwaves = gridDim.x * 4; E.wave = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (mask && blockIdx.y == 0) {                          // pixels with mask == 255, per wave (summed by k_reduce_partials)
+    E.nwaves = ncols * 4; E.wave = col * 4 + (threadIdx.x >> 6);
+    if (mask && a == 0) {                          // pixels with mask == 255, per wave (summed by k_reduce_partials)
         const uint32_t mc = wave_sum63((uint32_t)__popc(gather4(E.inm.x & 0x80808080u) | (gather4(E.inm.y & 0x80808080u) << 4)));
         if ((threadIdx.x & 63) == 63) maskpart[E.wave] = mc;
     }
@@ -469,10 +481,10 @@ __global__ __launch_bounds__(256, 4) void k_bg_stream(const uint8_t *__restrict_
     if (k <= kend) bg_step<0, PAD>(R, ring, E, src, k, a, kend, n);
     if (k + 1 <= kend) bg_step<1, PAD>(R, ring, E, src, k + 1, a, kend, n);
     if (k + 2 <= kend) bg_step<2, PAD>(R, ring, E, src, k + 2, a, kend, n);
-    if (b == n) {                                           // the last 12 frames share bg[n-12] = T11 of the final step
+    if (b == n) {                                           // the last 12 frames share bg[n-12] = T11 of the final step;
 #pragma unroll 1
-        for (int i = n - 12; i < n; i++) {
-            const uint2 img = ld_stream(src + (size_t)i * P + E.off8);
+        for (int i = n - 12; i < n; i++) {                   // their raw pixels are still in the ring (a <= n - 12)
+            const uint2 img = ring[(i & (BG_SLOTS - 1)) * 256];
             bg_emit<PAD>(E, img, px_split(img), R.last, i, true);
         }
     }
@@ -1625,6 +1637,11 @@ extern "C" int pseg_create(int device, int H, int W, int max_frames, pseg_ctx **
     ctx->own_stream = true;
     if (const char *e = getenv("PSEG_BG_CHUNKS")) ctx->bg_chunks = atoi(e) > 0 ? atoi(e) : 1;
     if (const char *e = getenv("PSEG_BG_GENERIC")) ctx->force_generic = atoi(e) != 0;
+    {
+        hipDeviceProp_t prop;                                // 4 blocks per CU (the kernel's launch bounds): see run_bg
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->bg_resident = 4 * prop.multiProcessorCount;
+        if (const char *e = getenv("PSEG_BG_TAIL")) ctx->bg_resident = atoi(e) > 0 ? atoi(e) : 0;   // 0: off, N: pretend N slots
+    }
     if (const char *e = getenv("PSEG_EXCLUSIVE")) ctx->exclusive = atoi(e) != 0;
     if (const char *e = getenv("PSEG_EARLY_RELEASE")) ctx->early_release = atoi(e) != 0;
     if (const char *e = getenv("PSEG_RUNS_OLD")) ctx->runs_old = atoi(e) != 0;
@@ -1742,7 +1759,8 @@ static int run_bg(pseg_ctx *ctx, const uint8_t *frames, int n_avail, int n_emit,
     ENSURE(ctx->partials, (size_t)n * npart * 4 * sizeof(uint32_t));
     ENSURE(ctx->maskpart, (size_t)npart * 4 + 16);
     { int r_ = head_setup(ctx, n); if (r_) return r_; }
-    int chunks = 1;
+    int chunks = 1, tailk = 1;
+    unsigned nfull = nblk;                                   // strips whose block walks its whole chunk
     if (stream) {
         ENSURE(ctx->trash, P + P / 8 + (size_t)npart * 16 + 256);
         // chunk bounds [chunks + 1] followed by the end of the batch each chunk lies in [chunks]
@@ -1760,23 +1778,42 @@ static int run_bg(pseg_ctx *ctx, const uint8_t *frames, int n_avail, int n_emit,
             bnd.resize(2 * chunks + 1);
             for (int c = 0; c < chunks; c++) { bnd[c] = (int)((long long)c * span / chunks); bnd[chunks + 1 + c] = n_kernel; }
             bnd[chunks] = n_emit;
+            // All blocks take the same time, so they run in rounds of bg_resident blocks and the last round is only partly
+            // filled (2560^2: 3200 strips on 1024 slots = 3 rounds + 128 strips).  The strips of that round are shared by
+            // tailk blocks each, which walk tailk shorter time ranges (11 halo frames more per range), so that the device
+            // stays filled to the end: 0.611 -> 0.585 ms.  Measured level (0.584 - 0.592 ms): 2944 - 3072 whole strips with
+            // the rest shared by 3 - 7 blocks; 2560 whole strips and 2 - 7 blocks for the rest: 0.591 - 0.605 ms.
+            const int res = ctx->bg_resident;
+            if (chunks == 1 && res > 0 && nblk > (unsigned)res && nblk % res) {
+                const unsigned rem = nblk % res;
+                tailk = (int)(res / rem);
+                if (tailk > 4) tailk = 4;
+                if (tailk > span / 24) tailk = span / 24;
+                if (tailk > 1) {
+                    nfull = nblk - rem;
+                    for (int c = 0; c < tailk; c++) bnd.push_back((int)((long long)c * span / tailk));
+                    bnd.push_back(n_emit);
+                } else tailk = 1;
+            }
         }
-        if (ctx->bounds_n != n_avail || ctx->bounds_emit != n_emit || ctx->bounds_chunks != chunks || ctx->bounds_batch != batch_len) {
+        if (ctx->bounds_n != n_avail || ctx->bounds_emit != n_emit || ctx->bounds_chunks != chunks || ctx->bounds_batch != batch_len ||
+            ctx->bounds_tailk != tailk) {
             ENSURE(ctx->bounds, bnd.size() * 4);
             HIPCHK(hipMemcpyAsync(ctx->bounds.p, bnd.data(), bnd.size() * 4, hipMemcpyHostToDevice, ctx->stream));
             HIPCHK(hipStreamSynchronize(ctx->stream));
             ctx->bounds_n = n_avail; ctx->bounds_emit = n_emit; ctx->bounds_chunks = chunks; ctx->bounds_batch = batch_len;
+            ctx->bounds_tailk = tailk;
         }
     }
     HIPCHK(hipEventRecord(ctx->ev[0], ctx->stream));
     if (stream && P % 2048 == 0)
-        hipLaunchKernelGGL(k_bg_stream<false>, dim3(nblk, chunks), dim3(256), 0, ctx->stream, frames, P, cleaned, mask, thr,
-                           (uint8_t *)ctx->bits.p, (uint4 *)ctx->partials.p, (const int *)ctx->bounds.p, (uint8_t *)ctx->trash.p,
-                           (uint32_t *)ctx->maskpart.p);
+        hipLaunchKernelGGL(k_bg_stream<false>, dim3(nfull + (nblk - nfull) * tailk, chunks), dim3(256), 0, ctx->stream, frames, P, cleaned,
+                           mask, thr, (uint8_t *)ctx->bits.p, (uint4 *)ctx->partials.p, (const int *)ctx->bounds.p, (uint8_t *)ctx->trash.p,
+                           (uint32_t *)ctx->maskpart.p, (int)nfull, tailk);
     else if (stream)
-        hipLaunchKernelGGL(k_bg_stream<true>, dim3(nblk, chunks), dim3(256), 0, ctx->stream, frames, P, cleaned, mask, thr,
-                           (uint8_t *)ctx->bits.p, (uint4 *)ctx->partials.p, (const int *)ctx->bounds.p, (uint8_t *)ctx->trash.p,
-                           (uint32_t *)ctx->maskpart.p);
+        hipLaunchKernelGGL(k_bg_stream<true>, dim3(nfull + (nblk - nfull) * tailk, chunks), dim3(256), 0, ctx->stream, frames, P, cleaned,
+                           mask, thr, (uint8_t *)ctx->bits.p, (uint4 *)ctx->partials.p, (const int *)ctx->bounds.p, (uint8_t *)ctx->trash.p,
+                           (uint32_t *)ctx->maskpart.p, (int)nfull, tailk);
     else
         for (int c = 0; c < nbatch; c++) {                   // the re-reading kernel takes one batch per launch
             const size_t f0 = (size_t)c * (batch_len ? batch_len : 0);

@@ -95,3 +95,26 @@ def test_batch_properties(full):
         own = hc[f][1][y:y + h, x:x + w] == tab.label[i]
         assert (msk[own] == 255).all()                                # the object's own pixels are in its mask
         assert tab.saved_props[s][5] == (msk == 255).sum()            # area_exc = pixels of the mask window
+
+
+def test_shared_strips_of_the_last_round_change_nothing(monkeypatch):
+    """At this size the background kernel has more blocks than the device holds; the strips of its last, partly filled
+    round are walked by several blocks in shorter time ranges.  Same results as with one block per strip."""
+    import torch
+    from imageprocessing_amd import synth
+    from imageprocessing_amd.engine import Segmenter
+    n = 75
+    out = []
+    for tail in ("1280", "0"):                             # 3200 strips on 1280 pretended slots: 640 strips shared by 2 blocks
+        monkeypatch.setenv("PSEG_BG_TAIL", tail)
+        seg = Segmenter(H, W, max_frames=n, device=0)
+        objs, off = synth.make_objects(n, H, W, 5, **synth.CONFIGS["pisco"])
+        frames = seg.synth_frames(n, 5, objs, off)
+        cleaned, ms, valid, tab = seg.process(frames, mask=seg.disk_mask(1200))
+        out.append((cleaned.clone(), np.array(ms), np.array(valid), tab.area.copy(), tab.props.copy(), tab.frame_mean.copy()))
+        seg.close()
+    a, b = out
+    assert torch.equal(a[0], b[0])
+    for x, y in zip(a[1:], b[1:]):
+        assert np.array_equal(x, y, equal_nan=x.dtype.kind == "f")
+    assert len(a[3]) > 100

@@ -102,12 +102,16 @@ def test_disk_mask(gpu_seg_factory):
         assert np.array_equal(seg.disk_mask(r).cpu().numpy(), helpers.make_disk(H, W, r))
 
 
-@pytest.mark.parametrize("n,chunks", [(12, 1), (13, 1), (27, 2), (28, 1), (29, 3), (45, 1), (61, 5), (200, 4)])
-def test_bg_stream_kernel_vs_oracle(monkeypatch, n, chunks):
-    """Streaming background kernel (one HBM read per raw byte) for every ring phase / chunking."""
+@pytest.mark.parametrize("n,chunks,slots", [(12, 1, 0), (13, 1, 0), (27, 2, 0), (28, 1, 0), (29, 3, 0), (45, 1, 0), (61, 5, 0),
+                                            (200, 4, 0), (61, 1, 3), (200, 1, 3), (97, 1, 3), (40, 1, 3)])
+def test_bg_stream_kernel_vs_oracle(monkeypatch, n, chunks, slots):
+    """Streaming background kernel (one HBM read per raw byte) for every ring phase / chunking; slots > 0: the strips of
+    the last, partly filled round of blocks are shared by several blocks (4 strips on 3 or 7 pretended slots)."""
     import torch
     from imageprocessing_amd.engine import Segmenter
     monkeypatch.setenv("PSEG_BG_CHUNKS", str(chunks))
+    if slots:
+        monkeypatch.setenv("PSEG_BG_TAIL", str(slots))
     H, W = 64, 128
     seg = Segmenter(H, W, max_frames=n, device=0)
     rng = np.random.default_rng(100 + n)
