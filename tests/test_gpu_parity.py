@@ -176,13 +176,20 @@ def test_detect_edge_cases(gpu_seg_factory):
     assert tab.n_rows == 0 and tab.crop_bytes == 0 and len(tab.saved_row) == 0
 
 
-def test_frame_range_parts_equal_whole_batch(gpu_seg_factory):
+@pytest.mark.parametrize("n,slots", [(61, 0), (130, 5)])
+def test_frame_range_parts_equal_whole_batch(gpu_seg_factory, monkeypatch, n, slots):
     """A batch cut into frame ranges (pseg_process_part with forward halos) gives byte-identical
-    cleaned frames, label maps and merged tables to the batch processed whole."""
+    cleaned frames, label maps and merged tables to the batch processed whole.  slots: the background kernel's 12 strips
+    on 5 pretended block slots, so that whole batch and parts share the strips of the last round between two blocks."""
     import torch
     from imageprocessing_amd import sharding
-    H, W, n = 128, 192, 61
-    seg = gpu_seg_factory(H, W)
+    from imageprocessing_amd.engine import Segmenter
+    H, W = 128, 192
+    if slots:
+        monkeypatch.setenv("PSEG_BG_TAIL", str(slots))
+        seg = Segmenter(H, W, max_frames=n, device=0)
+    else:
+        seg = gpu_seg_factory(H, W)
     stack, _, _ = _stack(n, H, W, 9, per_frame=14, dmin=15, dmax=300)
     stack[20] = 90                                        # corrupt frame in the middle part
     mask = torch.from_numpy(helpers.make_disk(H, W, 60)).cuda()
