@@ -13,7 +13,7 @@ NSUMS = 24
 SYMBOLS = [
     "pseg_create", "pseg_destroy", "pseg_last_error", "pseg_set_stream", "pseg_bgcorrect", "pseg_detect",
     "pseg_process", "pseg_process_part", "pseg_process_batches", "pseg_fetch_crops", "pseg_regionprops", "pseg_vit_tensors",
-    "pseg_disk_mask", "pseg_synth_frames", "pseg_last_ms",
+    "pseg_disk_mask", "pseg_resize_frames", "pseg_synth_frames", "pseg_last_ms",
 ]
 
 
@@ -71,11 +71,12 @@ def load():
     L.pseg_regionprops.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp]
     L.pseg_vit_tensors.argtypes = [vp, i32, i32, i32, vp, vp]
     L.pseg_disk_mask.argtypes = [vp, i32, vp]
+    L.pseg_resize_frames.argtypes = [vp, vp, i32, i32, i32, vp]
     L.pseg_synth_frames.argtypes = [vp, i32, i32, C.c_uint64, vp, vp, vp]
     L.pseg_last_ms.argtypes = [vp, i32]
     L.pseg_last_ms.restype = C.c_float
     for f in ("pseg_create", "pseg_destroy", "pseg_set_stream", "pseg_bgcorrect", "pseg_detect", "pseg_process", "pseg_process_part", "pseg_process_batches", "pseg_process_batches",
-              "pseg_fetch_crops", "pseg_regionprops", "pseg_vit_tensors", "pseg_disk_mask", "pseg_synth_frames"):
+              "pseg_fetch_crops", "pseg_regionprops", "pseg_vit_tensors", "pseg_disk_mask", "pseg_resize_frames", "pseg_synth_frames"):
         getattr(L, f).restype = i32
     _lib = L
     return L

@@ -10,6 +10,8 @@
 //                      region properties (detection.py:243-258, 75-159)
 // No MFMA: the path is byte/integer work bounded by HBM traffic and by latency on the sparse chain.
 #include <hip/hip_runtime.h>
+#include <cfloat>
+#include <cmath>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -68,7 +70,7 @@ struct pseg_ctx {
     DevBuf rows, saved_row, saved_geo, crop_off, bits_off, maskbits, crops_raw, crops_masked, crops_mask;
     bool mask_counted = false;    // maskcnt already holds the number of mask == 255 pixels (fused background kernel)
     bool have_bits = false;       // threshold plane + masked sums already produced by the bg kernel
-    DevBuf bounds, band_off, band_obj, trash, rp_small, rp_scratch;
+    DevBuf bounds, band_off, band_obj, trash, rp_small, rp_scratch, resize_tab;
     int bounds_n = -1, bounds_emit = -1, bounds_chunks = -1, bounds_batch = -1;
     bool runs_old = false;        // wave-per-row run extraction (k_runs) instead of k_runs_quad (PSEG_RUNS_OLD)
     bool exclusive = true;        // the device part of a call holds the GPU's turn (PSEG_EXCLUSIVE=0: batches interleave freely)
@@ -1661,7 +1663,7 @@ extern "C" int pseg_destroy(pseg_ctx *ctx)
                       &ctx->bg_parent, &ctx->bg_left, &ctx->minx, &ctx->maxx, &ctx->maxy, &ctx->area2,
                       &ctx->extrank, &ctx->keptrank, &ctx->savedrank, &ctx->objlabel, &ctx->objflag, &ctx->rows,
                       &ctx->saved_row, &ctx->saved_geo, &ctx->crop_off, &ctx->bits_off, &ctx->maskbits,
-                      &ctx->crops_raw, &ctx->crops_masked, &ctx->crops_mask, &ctx->bounds, &ctx->band_off, &ctx->band_obj, &ctx->trash, &ctx->rp_small, &ctx->rp_scratch};
+                      &ctx->crops_raw, &ctx->crops_masked, &ctx->crops_mask, &ctx->bounds, &ctx->band_off, &ctx->band_obj, &ctx->trash, &ctx->rp_small, &ctx->rp_scratch, &ctx->resize_tab};
     for (DevBuf *b : bufs) if (b->p) hipFree(b->p);
     for (PinBuf *b : {&ctx->pin_head, &ctx->pin_tail, &ctx->pin_nfg}) if (b->p) hipHostFree(b->p);
     for (auto &e : ctx->ev) if (e) hipEventDestroy(e);
@@ -2443,6 +2445,82 @@ extern "C" int pseg_disk_mask(pseg_ctx *ctx, int radius, uint8_t *mask)
     hipLaunchKernelGGL(k_fill_spans, dim3(H), dim3(256), 0, ctx->stream, mask, H, W, (const int32_t *)ctx->rowspans.p);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    return PSEG_OK;
+}
+
+// ---- cv.resize(img, (W, H)) of the reader (reader.py:79) -------------------------------------------
+// OpenCV's default interpolation (INTER_LINEAR) on 8-bit images is fixed-point arithmetic (imgproc resize.cpp): per output
+// column a source column sx and two 11-bit weights, per output row the same; a horizontal pass into 32-bit integers, a
+// vertical pass ((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2.  A reduction by exactly 2 x 2 is switched
+// to the area average (s00 + s01 + s10 + s11 + 2) >> 2 by the library.  The tables are made on the host with the library's
+// float / double operations; the kernel is integer only.  tab = xofs [W] | yofs [H] | alpha [2W] | beta [2H].
+__global__ void k_resize_linear(const uint8_t *__restrict__ src, int sh, int sw, uint8_t *__restrict__ dst, int H, int W,
+                                const int32_t *__restrict__ tab)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    const uint8_t *s = src + (size_t)blockIdx.z * sh * sw;
+    const int sx = tab[x], sy = tab[W + y];
+    const int a0 = tab[W + H + 2 * x], a1 = tab[W + H + 2 * x + 1], b0 = tab[3 * W + H + 2 * y], b1 = tab[3 * W + H + 2 * y + 1];
+    const int x1 = sx + 1 < sw ? sx + 1 : sw - 1;                                   // weight 0 there
+    const int y0 = sy < 0 ? 0 : (sy < sh ? sy : sh - 1), y1 = sy + 1 < 0 ? 0 : (sy + 1 < sh ? sy + 1 : sh - 1);
+    const int S0 = s[(size_t)y0 * sw + sx] * a0 + s[(size_t)y0 * sw + x1] * a1;
+    const int S1 = s[(size_t)y1 * sw + sx] * a0 + s[(size_t)y1 * sw + x1] * a1;
+    dst[((size_t)blockIdx.z * H + y) * W + x] = (uint8_t)((((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2);
+}
+__global__ void k_resize_half(const uint8_t *__restrict__ src, int sw, uint8_t *__restrict__ dst, int H, int W)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    const uint8_t *s = src + ((size_t)blockIdx.z * 2 * H + 2 * y) * sw + 2 * x;
+    dst[((size_t)blockIdx.z * H + y) * W + x] = (uint8_t)((s[0] + s[1] + s[sw] + s[sw + 1] + 2) >> 2);
+}
+static short resize_coef(float c)                            // saturate_cast<short>(c * INTER_RESIZE_COEF_SCALE): round to nearest even
+{
+    const long v = lrint((double)(c * 2048.f));
+    return (short)(v < -32768 ? -32768 : v > 32767 ? 32767 : v);
+}
+extern "C" int pseg_resize_frames(pseg_ctx *ctx, const uint8_t *src, int n, int sh, int sw, uint8_t *dst)
+{
+    if (!ctx) return PSEG_ERR_ARG;
+    if (!src || !dst || n < 1 || sh < 1 || sw < 1 || sh > 32767 || sw > 32767) return fail(ctx, PSEG_ERR_ARG, "resize: bad source shape");
+    HIPCHK(hipSetDevice(ctx->device));
+    const int H = ctx->H, W = ctx->W;
+    hipStream_t st = ctx->stream;
+    if (sh == H && sw == W) {                                // same size: cv.resize returns a copy
+        HIPCHK(hipMemcpyAsync(dst, src, (size_t)n * H * W, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));
+        return PSEG_OK;
+    }
+    const double inv_x = (double)W / sw, inv_y = (double)H / sh, scale_x = 1. / inv_x, scale_y = 1. / inv_y;
+    const dim3 grid(nblocks((size_t)W), H, n);
+    if (std::fabs(scale_x - 2.) < DBL_EPSILON && std::fabs(scale_y - 2.) < DBL_EPSILON) {
+        hipLaunchKernelGGL(k_resize_half, grid, dim3(256), 0, st, src, sw, dst, H, W);
+    } else {
+        std::vector<int32_t> tab((size_t)3 * W + 3 * H);
+        for (int dx = 0; dx < W; dx++) {
+            float fx = (float)((dx + 0.5) * scale_x - 0.5);
+            int sx = (int)std::floor(fx);
+            fx -= sx;
+            if (sx < 0) { fx = 0; sx = 0; }
+            if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+            tab[dx] = sx;
+            tab[W + H + 2 * dx] = resize_coef(1.f - fx); tab[W + H + 2 * dx + 1] = resize_coef(fx);
+        }
+        for (int dy = 0; dy < H; dy++) {                     // rows are clamped when they are read, their weights are not touched
+            float fy = (float)((dy + 0.5) * scale_y - 0.5);
+            const int sy = (int)std::floor(fy);
+            fy -= sy;
+            tab[W + dy] = sy;
+            tab[3 * W + H + 2 * dy] = resize_coef(1.f - fy); tab[3 * W + H + 2 * dy + 1] = resize_coef(fy);
+        }
+        ENSURE(ctx->resize_tab, tab.size() * 4);
+        HIPCHK(hipMemcpyAsync(ctx->resize_tab.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));                    // tab leaves scope
+        hipLaunchKernelGGL(k_resize_linear, grid, dim3(256), 0, st, src, sh, sw, dst, H, W, (const int32_t *)ctx->resize_tab.p);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
     return PSEG_OK;
 }
 

@@ -120,6 +120,21 @@ class Segmenter:
         self._chk(self.L.pseg_disk_mask(self.h, int(radius), m.data_ptr()))
         return m
 
+    def resize_frames(self, src, out=None):
+        """``cv.resize(img, (W, H))`` of the reader (reader.py:79: OpenCV's default INTER_LINEAR on uint8) for a stack of
+        frames ``src`` uint8 ``[n, sh, sw]`` on this device -> ``[n, H, W]``.  Decoded frames are uploaded at their native
+        size and resized here instead of on the host."""
+        import torch
+        if src.dim() == 2:
+            src = src[None]
+        if src.dtype != torch.uint8 or src.dim() != 3 or not src.is_cuda or not src.is_contiguous():
+            raise PsegError("resize_frames: need a contiguous uint8 CUDA tensor [n, sh, sw]")
+        n, sh, sw = src.shape
+        if out is None:
+            out = torch.empty((n, self.H, self.W), dtype=torch.uint8, device=src.device)
+        self._chk(self.L.pseg_resize_frames(self.h, src.data_ptr(), int(n), int(sh), int(sw), out.data_ptr()))
+        return out
+
     def bgcorrect(self, frames, n_bg_imgs=6, cleaned=None):
         import torch
         n = frames.shape[0]

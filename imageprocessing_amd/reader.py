@@ -3,7 +3,9 @@
 ``ReaderOutput.images[i] = (img, fn)`` is the contract the background stage consumes
 (reader.py:16-51).  Decoding is I/O outside the GPU path: ``read_img`` uses
 PIL instead of cv2 (grayscale, bilinear resize to 2560x2560 only when the size differs), so decoded
-pixels of JPEGs / resized frames are not claimed bit-identical to OpenCV's."""
+pixels of JPEGs / resized frames are not claimed bit-identical to OpenCV's.  ``run_reader(..., native=True)``
+leaves the frames at their decoded size; ``Segmenter.resize_frames`` then applies OpenCV's resize arithmetic
+(INTER_LINEAR, reader.py:79) on the device after the upload."""
 import os
 import threading
 from concurrent.futures import ThreadPoolExecutor
@@ -24,8 +26,8 @@ class ReaderOutput:
             self.images[index] = (img, fn)
 
 
-def read_img(output, input, thread_index=0):
-    """reader.py:54-82."""
+def read_img(output, input, thread_index=0, native=False):
+    """reader.py:54-82.  native: no resize here (frames go to ``Segmenter.resize_frames`` on the device)."""
     from PIL import Image
     file, img_index = input
     fn = os.path.basename(file)
@@ -34,15 +36,15 @@ def read_img(output, input, thread_index=0):
         return
     try:
         im = Image.open(file).convert("L")
-        if im.size != (2560, 2560):
+        if not native and im.size != (2560, 2560):
             im = im.resize((2560, 2560), Image.BILINEAR)
         output.add_output(np.ascontiguousarray(np.asarray(im, dtype=np.uint8)), fn, img_index)
     except Exception as e:                       # reference: print and carry on (reader.py:81-82)
         print("...exception occurred:", e)
 
 
-def run_reader(files, output, n_threads, resize):
-    """reader.py:86-110: ``files`` is a list of (path, index)."""
+def run_reader(files, output, n_threads, resize, native=False):
+    """reader.py:86-110: ``files`` is a list of (path, index).  (The reference ignores ``resize`` and always resizes.)"""
     with ThreadPoolExecutor(max_workers=max(1, n_threads)) as ex:
-        list(ex.map(lambda f: read_img(output, f), files))
+        list(ex.map(lambda f: read_img(output, f, native=native), files))
     print("all files in batch added to reader pool")

@@ -148,6 +148,12 @@ int pseg_vit_tensors(pseg_ctx *ctx, int plane, int first, int count, float *out,
 /* cv.circle(mask, (W/2, H/2), radius, 255, -1) on the device (detection.py:315-326). mask [dev] u8[H][W]. */
 int pseg_disk_mask(pseg_ctx *ctx, int radius, uint8_t *mask);
 
+/* cv.resize(img, (2560, 2560)) of the reader (reader.py:79), i.e. OpenCV's INTER_LINEAR on 8-bit images, for n frames
+ * of sh x sw pixels into the context's H x W: the library's 11-bit fixed-point weights and two-pass rounding; the area
+ * average it substitutes for a reduction by exactly 2 x 2; a plain copy for equal sizes.  src [dev] u8[n][sh][sw];
+ * dst [dev] u8[n][H][W].  SURVEY.md 8(f) N4a: decoding stays on the host, frames are uploaded at their native size. */
+int pseg_resize_frames(pseg_ctx *ctx, const uint8_t *src, int n, int sh, int sw, uint8_t *dst);
+
 /* Synthetic PISCO-like frames rendered on the device (bench / tests; no counterpart in the
  * reference).  objs [host] int32[n_obj][8] = cx,cy,a,b,cosQ12,sinQ12,contrast,kind;
  * frame_obj_off [host] int32[n+1]; out [dev] u8[n][H][W]. */
