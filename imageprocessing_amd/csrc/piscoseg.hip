@@ -1648,7 +1648,7 @@ extern "C" int pseg_create(int device, int H, int W, int max_frames, pseg_ctx **
     if (const char *e = getenv("PSEG_EARLY_RELEASE")) ctx->early_release = atoi(e) != 0;
     if (const char *e = getenv("PSEG_RUNS_OLD")) ctx->runs_old = atoi(e) != 0;
     if (const char *e = getenv("PSEG_NO_BANDS")) ctx->no_bands = atoi(e) != 0;
-    for (auto &e : ctx->ev) if (hipEventCreate(&e) != hipSuccess) { delete ctx; return PSEG_ERR_HIP; }
+    for (auto &e : ctx->ev) if (hipEventCreate(&e) != hipSuccess) { pseg_destroy(ctx); return PSEG_ERR_HIP; }   // frees what exists so far
     *out = ctx;
     return PSEG_OK;
 }
