@@ -771,6 +771,20 @@ __global__ void k_unions(SegState S, int nfg, int nt, int bandh)
     if (g < (size_t)nt) bg_union_body(S, (int)g, nfg, bandh);
 }
 
+// unions across the band boundaries only: block = the first row of a band (y = BAND_H, 2 BAND_H, ...) of one frame, a
+// thread per run (its foreground unions with the row above, and the gap on its left) plus one for the trailing gap.  The
+// per-element launch (k_unions over all runs and gaps) has one thread in BAND_H with work.
+__global__ __launch_bounds__(64) void k_unions_rows(SegState S, int bandh)
+{
+    const int f = blockIdx.y, y = ((int)blockIdx.x + 1) * bandh;
+    if (y >= S.H) return;
+    const int rs = seg_rowstart(S, f, y), n = seg_rowcount(S, f, y);
+    for (int j = threadIdx.x; j <= n; j += 64) {
+        if (j < n) fg_union_body(S, rs + j);
+        bg_union_elem(S, f, y, j);
+    }
+}
+
 // ---- band-local labelling in LDS ----------------------------------------------------------------------------------
 // Block = one band of BAND_H rows of one frame.  The band's runs and gaps are united with a union-find that lives in
 // LDS (same rules as fg_union_body / bg_union_elem, local indices), flattened, and written to the global parent arrays
@@ -2009,7 +2023,7 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
     if (bandmax <= BAND_CAP && !ctx->no_bands) {
         // bands of BAND_H rows are labelled in LDS; the global kernels only unite across the band boundaries
         hipLaunchKernelGGL(k_band_label, dim3((H + BAND_H - 1) / BAND_H, n), dim3(256), 0, st, S);
-        hipLaunchKernelGGL(k_unions, dim3(nblocks(nbg)), dim3(256), 0, st, S, nfg, nbg, BAND_H);
+        if (H > BAND_H) hipLaunchKernelGGL(k_unions_rows, dim3((H - 1) / BAND_H, n), dim3(64), 0, st, S, BAND_H);
     } else {
         hipLaunchKernelGGL(k_init, dim3(nblocks(nbg)), dim3(256), 0, st, S, nfg, nbg);
         hipLaunchKernelGGL(k_unions, dim3(nblocks(nbg)), dim3(256), 0, st, S, nfg, nbg, 0);
