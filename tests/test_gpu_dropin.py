@@ -156,6 +156,10 @@ def test_abi_error_paths_return_codes_and_text():
     m = torch.zeros((8, 8), dtype=torch.uint8, device="cuda")
     assert L.pseg_regionprops(seg.h, m.data_ptr(), m.data_ptr(), 8, 8, 8, props.ctypes.data, None) == -1    # empty mask
     assert np.isnan(props).all()
+    assert L.pseg_resize_frames(seg.h, None, 1, 8, 8, m.data_ptr()) == -1 and b"resize" in L.pseg_last_error(seg.h)
+    assert L.pseg_resize_frames(seg.h, m.data_ptr(), 1, 0, 8, m.data_ptr()) == -1
+    with pytest.raises(PsegError):
+        seg.resize_frames(torch.zeros((1, 8, 8), dtype=torch.float32, device="cuda"))
     # the context still works after the errors
     cleaned, ms, valid = seg.bgcorrect(torch.full((12, 64, 128), 7, dtype=torch.uint8, device="cuda"))
     assert valid.sum() == 0 and np.allclose(ms[:, 0], 7.0)
