@@ -1,3 +1,4 @@
+# kernel trace of bench.py --streams 3; was used with an experimental PSEG_DEFER=1 switch that is no longer in the source (profiles/README.md): without it this traces the plain turn
 set -e
 R=$PWD
 export TMPDIR=/tmp PSEG_DEFER=1
