@@ -1336,7 +1336,44 @@ __global__ __launch_bounds__(CROP_THREADS) void k_crops_sums(SegState S, int n_s
     const long long off = crop_off[s] + (long long)r0 * w;
     uint8_t *o_raw = c_raw + off, *o_mask = c_mask + off, *o_masked = c_masked + off;
     uint32_t isum = 0, mn_e = 0x00ff00ffu, mn_o = 0x00ff00ffu, mx_e = 0, mx_o = 0;   // intensities: byte lanes as u16 pairs
-    if (w >= 8) {
+    if (w >= 16) {
+        // thread = 16 consecutive pixels of a row (the 8-pixel form below with 128-bit accesses)
+        const int cpr = (w + 15) >> 4, nitem = nrows * cpr;
+        const float rcp = 1.0f / (float)cpr;
+#pragma unroll CROP_UNROLL
+        for (int p = threadIdx.x; p < nitem; p += CROP_THREADS) {
+            int yl = (int)((float)p * rcp);
+            int c = p - (int)__umul24((uint32_t)yl, (uint32_t)cpr);
+            if (c < 0) { yl--; c += cpr; } else if (c >= cpr) { yl++; c -= cpr; }
+            int xx = 16 * c;
+            const int over = xx - (w - 16);               // > 0 only for the last chunk of a row when w % 16 != 0
+            if (over > 0) xx = w - 16;
+            const uint32_t *mw = mb + __umul24((uint32_t)yl, (uint32_t)wpr) + (xx >> 5);
+            const uint32_t bits16 = __builtin_amdgcn_alignbit(mw[1], mw[0], (uint32_t)(xx & 31)) & 0xffffu;
+            const uint32_t so = __umul24((uint32_t)yl, (uint32_t)S.W) + (uint32_t)xx, qo = __umul24((uint32_t)yl, (uint32_t)w) + (uint32_t)xx;
+            uint32_t cv[4], rv[4], m[4], cm[4];
+            __builtin_memcpy(cv, sb + so, 16);
+            if (same) { rv[0] = cv[0]; rv[1] = cv[1]; rv[2] = cv[2]; rv[3] = cv[3]; } else __builtin_memcpy(rv, rb + so, 16);
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                const uint32_t m1 = __umul24((bits16 >> (4 * d)) & 0xfu, 0x00204081u) & 0x01010101u;
+                m[d] = (m1 << 8) - m1;
+                cm[d] = (cv[d] & m[d]) | ~m[d];
+            }
+            __builtin_memcpy(o_raw + qo, rv, 16);
+            __builtin_memcpy(o_mask + qo, m, 16);
+            __builtin_memcpy(o_masked + qo, cm, 16);
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                const int nb = over - 4 * d;              // bytes of this dword that belong to the neighbour chunk
+                const uint32_t keep = nb <= 0 ? 0xffffffffu : (nb >= 4 ? 0u : 0xffffffffu << (8 * nb));
+                const uint32_t mk = m[d] & keep, in4 = cv[d] & mk, out4 = cv[d] | ~mk;
+                isum = __builtin_amdgcn_sad_u8(in4, 0u, isum);
+                mx_e = pkmax(mx_e, __builtin_amdgcn_perm(0, in4, 0x0c020c00)); mx_o = pkmax(mx_o, __builtin_amdgcn_perm(0, in4, 0x0c030c01));
+                mn_e = pkmin(mn_e, __builtin_amdgcn_perm(0, out4, 0x0c020c00)); mn_o = pkmin(mn_o, __builtin_amdgcn_perm(0, out4, 0x0c030c01));
+            }
+        }
+    } else if (w >= 8) {
         // thread = 8 consecutive pixels of a row: one (unaligned) 64-bit load / store per plane; the last chunk of a row is
         // shifted back to end at the row end, `keep` drops the bytes it shares with its neighbour from the sums (as below;
         // half the index arithmetic and half the memory instructions per pixel of the 4-pixel form)
