@@ -125,6 +125,21 @@ def test_calculate_regionprops_signature():
                 np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-7, err_msg=f"case {case} {k}")
 
 
+def test_regionprops_of_tall_filled_windows():
+    """Solid windows over a thousand rows tall and a few pixels to a few dozen pixels wide: the largest row moments a row
+    band of the crop kernel can see (its band-local sums are 32-bit)."""
+    from imageprocessing_amd import detection
+    from oracle import regionprops_ref
+    rng = np.random.default_rng(11)
+    for h, w in [(1500, 12), (1300, 18), (2000, 40), (1100, 55), (900, 70)]:
+        mask = np.full((h, w), 255, np.uint8)
+        img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        got = detection.calculate_regionprops(mask, img)
+        want = regionprops_ref.calculate_regionprops(mask, img)
+        for k in want:
+            np.testing.assert_allclose(float(got[k]), float(want[k]), rtol=1e-5, atol=1e-7, err_msg=f"{h}x{w} {k}")
+
+
 def test_abi_error_paths_return_codes_and_text():
     """Every entry point returns a negative code with a message instead of aborting (the reference's convention is
     'print and carry on'); nothing here launches a kernel with bad shapes."""
