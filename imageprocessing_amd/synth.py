@@ -89,5 +89,8 @@ def render(n_frames, H, W, seed, objs, off, frame0=0):
 CONFIGS = {
     # BASELINE.json configs (object statistics only; frame counts are chosen by the caller)
     "pisco": dict(per_frame=50, dmin=8.0, dmax=300.0, ring_frac=0.2),
-    "uvp5_dense": dict(per_frame=2000, dmin=2.0, dmax=12.0, ring_frac=0.0),
+    "uvp5_dense": dict(per_frame=2000, dmin=2.0, dmax=12.0, ring_frac=0.0),     # configs[3]: every object below the save threshold
+    # the same density with larger particles: ~550 saved objects per frame (area > 400), overlapping bounding boxes -- the
+    # per-object crop / property / hull kernels and the cumulative mask under density
+    "uvp5_dense_saved": dict(per_frame=2000, dmin=8.0, dmax=40.0, ring_frac=0.1),
 }

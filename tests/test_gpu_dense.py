@@ -1,0 +1,107 @@
+"""BASELINE.json configs[3] -- UVP5-like density, ~2000 small particles per frame -- through the C ABI against the oracle
+(detection.py:222-273 under density: many kept rows, overlapping bounding boxes, the cumulative mask).  Two workloads:
+``uvp5_dense`` (diameters 2-12 px: rows, but no object above min_area_to_save) and ``uvp5_dense_saved`` (diameters 8-40 px:
+~550 saved objects per frame).  At 512 x 512 the particle density per pixel and the pixel diameters are those of the full
+frame and every frame is compared with the oracle; at 2560 x 2560 one frame is compared with the oracle and the batch
+through the size-independent properties."""
+import numpy as np
+import pytest
+
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+def _scaled(cfg_name, W):
+    """the config's object statistics at frame width W: same particles per pixel, same diameters in pixels"""
+    from imageprocessing_amd import synth
+    cfg = dict(synth.CONFIGS[cfg_name])
+    sc = 2560 / W
+    cfg["per_frame"] = int(round(cfg["per_frame"] / sc / sc))
+    cfg["dmin"] *= sc                                      # make_objects scales diameters by W / 2560
+    cfg["dmax"] *= sc
+    return cfg
+
+
+@pytest.mark.parametrize("cfg_name,min_saved", [("uvp5_dense", 0), ("uvp5_dense_saved", 10)])
+def test_dense_parity_small(gpu_seg_factory, cfg_name, min_saved):
+    import torch
+    from imageprocessing_amd import synth
+    H = W = 512
+    n = 13
+    seg = gpu_seg_factory(H, W)
+    objs, off = synth.make_objects(n, H, W, 4, **_scaled(cfg_name, W))
+    stack = synth.render(n, H, W, 4, objs, off)
+    mask = helpers.make_disk(H, W, 240)
+    items = helpers.oracle_bgcorrect(stack)
+    dets = helpers.oracle_detect(items, mask)
+    labels = torch.empty((n, H, W), dtype=torch.int32, device="cuda")
+    cleaned, ms, valid, tab = seg.process(torch.from_numpy(stack).cuda(), mask=torch.from_numpy(mask).cuda(), labels=labels,
+                                          fetch_crops=True)
+    cl = cleaned.cpu().numpy()
+    for i, it in enumerate(items):
+        assert np.array_equal(cl[i], it[1])
+    helpers.compare_table(tab, dets, H, W, labels=labels.cpu().numpy())
+    per_frame = np.diff(tab.frame_row_offset)
+    assert per_frame.min() >= 30, per_frame                # 80 particles per frame, most of them kept rows
+    saved = np.bincount(tab.frame[tab.saved == 1], minlength=n)
+    assert saved.min() >= min_saved, saved
+    if min_saved == 0:
+        assert tab.saved.sum() == 0                        # configs[3] as BASELINE.json words it: nothing above 400 px^2
+
+
+def test_dense_saved_lower_save_threshold(gpu_seg_factory):
+    """configs[3] particles with min_area_to_save lowered to 30: nearly every kept row is saved -- hundreds of tiny windows
+    (narrower than 16 / 8 / 4 px: every copy path of the crop kernel) with neighbours inside their bounding boxes"""
+    import torch
+    from imageprocessing_amd import synth
+    H = W = 512
+    n = 12
+    seg = gpu_seg_factory(H, W)
+    objs, off = synth.make_objects(n, H, W, 14, **_scaled("uvp5_dense", W))
+    stack = synth.render(n, H, W, 14, objs, off)
+    mask = helpers.make_disk(H, W, 240)
+    items = helpers.oracle_bgcorrect(stack)
+    dets = helpers.oracle_detect(items, mask, min_area_to_save=30)
+    labels = torch.empty((n, H, W), dtype=torch.int32, device="cuda")
+    tab = seg.process(torch.from_numpy(stack).cuda(), mask=torch.from_numpy(mask).cuda(), labels=labels, fetch_crops=True,
+                      min_area_to_save=30.0)[3]
+    helpers.compare_table(tab, dets, H, W, labels=labels.cpu().numpy())
+    assert tab.saved.sum() >= 15 * n
+
+
+@pytest.mark.parametrize("cfg_name", ["uvp5_dense", "uvp5_dense_saved"])
+def test_dense_fullsize(cfg_name):
+    """2560 x 2560, 2000 particles per frame: one frame completely against the oracle, the batch through the properties"""
+    import torch
+    from imageprocessing_amd import synth
+    from imageprocessing_amd.engine import Segmenter
+    H = W = 2560
+    n = 16
+    seg = Segmenter(H, W, max_frames=n, device=0)
+    try:
+        objs, off = synth.make_objects(n, H, W, 4, **synth.CONFIGS[cfg_name])
+        frames = seg.synth_frames(n, 4, objs, off)
+        mask = seg.disk_mask(1200)
+        labels = torch.empty((n, H, W), dtype=torch.int32, device="cuda")
+        cleaned, ms, valid, tab = seg.process(frames, mask=mask, labels=labels, fetch_crops=True)
+        rows = np.diff(tab.frame_row_offset)
+        assert rows.min() > 800, rows                       # ~2000 particles, those below 10 px^2 dropped
+        saved = np.bincount(tab.frame[tab.saved == 1], minlength=n)
+        if cfg_name == "uvp5_dense_saved":
+            assert saved.min() >= 450, saved
+        else:
+            assert saved.sum() == 0
+        # every cleaned frame against the torch restatement of bg_correction.py:72-81
+        want, s1, s2 = helpers.torch_bgcorrect(frames)
+        assert torch.equal(cleaned, want)
+        m, sd = helpers.mean_std_from_sums(s1.astype(np.float64), s2.astype(np.float64), float(H * W))
+        np.testing.assert_allclose(ms[:, 0], m, rtol=1e-12)
+        np.testing.assert_allclose(ms[:, 1], sd, rtol=1e-9)
+        helpers.check_batch_properties(tab, labels, cleaned, mask, n_rows_sample=150, n_crops_sample=80)
+        stack = frames.cpu().numpy()
+        images = [(stack[i], f"img_{i:05d}.png") for i in range(n)]
+        nrows, nsaved = helpers.compare_frame_with_oracle(tab, labels, cleaned, ms, 2, images, mask.cpu().numpy())
+        assert nrows == rows[2] and nsaved == saved[2]
+    finally:
+        seg.close()

@@ -34,67 +34,15 @@ def test_two_frames_against_the_oracle(full):
     hmask = full["mask"].cpu().numpy()
     assert np.array_equal(hmask, helpers.make_disk(H, W, 1200))
     images = [(stack[i], f"img_{i:05d}.png") for i in range(N)]
-    tab, labels = full["tab"], full["labels"]
     for i in (3, N - 2):                                   # an ordinary frame and one inside the shared tail window
-        it = helpers.ref.correct_img(i, images, 6)
-        assert np.array_equal(full["cleaned"][i].cpu().numpy(), it[1])
-        np.testing.assert_allclose(full["ms"][i], it[2], rtol=1e-9)
-        d = helpers.ref.detect_on_img((it[0].copy(), it[1].copy(), it[2], it[3]), hmask, want_labels=True)
-        assert np.array_equal(labels[i].cpu().numpy(), d["labels"])
-        a, b = tab.frame_row_offset[i], tab.frame_row_offset[i + 1]
-        assert b - a == len(d["rows"])
-        props = tab.props
-        for k, row in enumerate(d["rows"]):
-            assert tab.area[a + k] == row[6] and tab.saved[a + k] == row[11]
-            if row[11]:
-                assert (tab.x[a + k], tab.y[a + k], tab.w[a + k], tab.h[a + k]) == tuple(row[7:11])
-                np.testing.assert_allclose(props[a + k], np.array([float(v) for v in row[12:]]), rtol=1e-5, atol=1e-7)
+        helpers.compare_frame_with_oracle(full["tab"], full["labels"], full["cleaned"], full["ms"], i, images, hmask)
 
 
 def test_batch_properties(full):
-    import torch
-    tab, labels, cleaned, mask = full["tab"], full["labels"], full["cleaned"], full["mask"]
+    tab, labels = full["tab"], full["labels"]
     assert full["valid"][7] == 0 and tab.frame_valid[7] == 0
     assert tab.frame_row_offset[8] == tab.frame_row_offset[7] and int(labels[7].max()) == 0
-    inside = mask == 255
-    cnt = int(inside.sum())
-    for f in range(N):
-        if not tab.frame_valid[f]:
-            continue
-        corr = (255 - cleaned[f].to(torch.int64)) * inside            # detection.py:178-188, exact integers
-        s1, s2 = int(corr.sum()), int((corr * corr).sum())
-        np.testing.assert_allclose(tab.frame_mean[f], s1 / cnt, rtol=1e-12)
-        np.testing.assert_allclose(tab.frame_std[f], np.sqrt(s2 / cnt - (s1 / cnt) ** 2), rtol=1e-9)
-        lab = labels[f]
-        assert int(lab.max()) == tab.frame_n_contours[f]
-        # labelled pixels are exactly the thresholded pixels that belong to external components
-        thr = corr > 10
-        assert bool((lab > 0).logical_and(~thr).any()) is False
-    # label map <-> table: the pixels of a kept object's label span exactly its bounding box
-    rng = np.random.default_rng(0)
-    for i in rng.choice(tab.n_rows, 60, replace=False):
-        f, k = int(tab.frame[i]), int(tab.label[i])
-        ys, xs = torch.nonzero(labels[f] == k, as_tuple=True)
-        assert len(ys) > 0
-        box = (int(xs.min()), int(ys.min()), int(xs.max() - xs.min()) + 1, int(ys.max() - ys.min()) + 1)
-        assert box == (tab.x[i], tab.y[i], tab.w[i], tab.h[i])
-        assert len(ys) <= 2 * tab.area[i] + 2 * (tab.w[i] + tab.h[i]) + 4       # area bounds the pixel count (Pick)
-    # crop identities (detection.py:243-247)
-    assert tab.crop_bytes == int((tab.w[tab.saved_row].astype(np.int64) * tab.h[tab.saved_row]).sum())
-    hc = {}
-    for s in rng.choice(len(tab.saved_row), 40, replace=False):
-        i = int(tab.saved_row[s])
-        f = int(tab.frame[i])
-        if f not in hc:
-            hc[f] = (cleaned[f].cpu().numpy(), labels[f].cpu().numpy())
-        x, y, w, h = tab.x[i], tab.y[i], tab.w[i], tab.h[i]
-        raw, msk, msd = tab.crop(s, "raw"), tab.crop(s, "mask"), tab.crop(s, "masked")
-        assert np.array_equal(raw, hc[f][0][y:y + h, x:x + w])
-        assert set(np.unique(msk)) <= {0, 255}
-        assert np.array_equal(msd, np.where(msk == 255, raw, 255))
-        own = hc[f][1][y:y + h, x:x + w] == tab.label[i]
-        assert (msk[own] == 255).all()                                # the object's own pixels are in its mask
-        assert tab.saved_props[s][5] == (msk == 255).sum()            # area_exc = pixels of the mask window
+    helpers.check_batch_properties(tab, labels, full["cleaned"], full["mask"])
 
 
 def test_shared_strips_of_the_last_round_change_nothing(monkeypatch):
@@ -118,3 +66,69 @@ def test_shared_strips_of_the_last_round_change_nothing(monkeypatch):
     for x, y in zip(a[1:], b[1:]):
         assert np.array_equal(x, y, equal_nan=x.dtype.kind == "f")
     assert len(a[3]) > 100
+
+
+def test_bench_configuration_200_frames_three_contexts():
+    """Exactly what bench.py times: 200-frame batches at 2560 x 2560, the device's real block-slot count (no PSEG_BG_TAIL
+    override: the strips of the last round are shared by 4 blocks), three contexts on three host threads taking turns on
+    the GPU.  Every cleaned frame and the raw statistics against the torch restatement of bg_correction.py:72-81, the three
+    contexts against each other, label map <-> table on every frame, two frames completely against the oracle."""
+    import os
+    import threading
+    import torch
+    from imageprocessing_amd import synth
+    from imageprocessing_amd.engine import Segmenter
+    assert "PSEG_BG_TAIL" not in os.environ and "PSEG_BG_CHUNKS" not in os.environ
+    n, ns = 200, 3
+    segs = [Segmenter(H, W, max_frames=n, device=0) for _ in range(ns)]
+    try:
+        objs, off = synth.make_objects(n, H, W, 2, **synth.CONFIGS["pisco"])
+        frames = segs[0].synth_frames(n, 2, objs, off)
+        frames[41] = 200                                   # corrupt frames: one in the body, one in the shared tail window
+        frames[195] = 3
+        mask = segs[0].disk_mask(1200)
+        cleaned = [torch.empty((n, H, W), dtype=torch.uint8, device="cuda") for _ in range(ns)]
+        labels = [torch.empty((n, H, W), dtype=torch.int32, device="cuda") for _ in range(ns)]
+        torch.cuda.synchronize()
+        res, err = [None] * ns, []
+
+        def work(k):
+            try:
+                for rep in range(2):                       # two calls per context: the turns interleave like in the bench
+                    res[k] = segs[k].process(frames, mask=mask, cleaned=cleaned[k], labels=labels[k], fetch_crops=(rep == 1))
+            except Exception as e:                         # noqa: BLE001
+                err.append(e)
+        ths = [threading.Thread(target=work, args=(k,)) for k in range(ns)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        assert not err, err
+        want, s1, s2 = helpers.torch_bgcorrect(frames)
+        m, sd = helpers.mean_std_from_sums(s1.astype(np.float64), s2.astype(np.float64), float(H * W))
+        ok = np.ones(n, bool)
+        ok[[41, 195]] = False
+        tab0 = res[0][3]
+        for k in range(ns):
+            c, ms, valid, tab = res[k]
+            assert np.array_equal(valid.astype(bool), ok)
+            assert torch.equal(c[ok], want[ok])
+            np.testing.assert_allclose(ms[:, 0], m, rtol=1e-12)
+            np.testing.assert_allclose(ms[:, 1], sd, rtol=1e-9, atol=1e-12)
+            if k:
+                assert torch.equal(labels[k], labels[0])
+                for name in ("frame_row_offset", "frame_n_contours", "frame_valid", "frame_mean", "frame_std", "frame", "c",
+                             "label", "area", "x", "y", "w", "h", "saved", "saved_props", "saved_row", "crop_offset", "sums"):
+                    assert np.array_equal(getattr(tab, name), getattr(tab0, name), equal_nan=True), name
+                for plane in ("raw", "masked", "mask"):
+                    assert np.array_equal(tab.crops[plane], tab0.crops[plane])
+        assert tab0.n_rows > 5000 and tab0.saved.sum() > 3000
+        helpers.check_batch_properties(tab0, labels[0], cleaned[0], mask, n_rows_sample=200, n_crops_sample=100)
+        stack = frames.cpu().numpy()
+        images = [(stack[i], f"img_{i:05d}.png") for i in range(n)]
+        hmask = mask.cpu().numpy()
+        for i in (100, 193):                               # the body of the batch and the shared tail window
+            helpers.compare_frame_with_oracle(tab0, labels[0], cleaned[0], res[0][1], i, images, hmask)
+    finally:
+        for s in segs:
+            s.close()
