@@ -12,7 +12,7 @@ NSUMS = 24
 
 SYMBOLS = [
     "pseg_create", "pseg_destroy", "pseg_last_error", "pseg_set_stream", "pseg_bgcorrect", "pseg_detect",
-    "pseg_process", "pseg_process_part", "pseg_process_batches", "pseg_fetch_crops", "pseg_regionprops", "pseg_vit_tensors",
+    "pseg_process", "pseg_process_part", "pseg_process_batches", "pseg_fetch_crops", "pseg_regionprops", "pseg_regionprops_noalloc", "pseg_vit_tensors",
     "pseg_disk_mask", "pseg_resize_frames", "pseg_synth_frames", "pseg_last_ms",
 ]
 
@@ -55,6 +55,13 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(there is no CPU fallback)")
+    try:
+        # torch ships its own libamdhip64.so.7 / libhsa-runtime64; a process holds one HIP runtime per SONAME, and torch finds
+        # no GPU when the system copy was mapped first (this library links against it).  Tensors are this binding's device
+        # memory, so torch goes first and the library binds to the runtime torch brought.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, i32, dbl = C.c_void_p, C.c_int, C.c_double
     L.pseg_create.argtypes = [i32, i32, i32, i32, C.POINTER(vp)]
@@ -69,6 +76,7 @@ def load():
     L.pseg_process_batches.argtypes = [vp, vp, i32, i32, i32, vp, i32, dbl, dbl, vp, vp, vp, vp, C.POINTER(Table)]
     L.pseg_fetch_crops.argtypes = [vp, vp, vp, vp]
     L.pseg_regionprops.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp]
+    L.pseg_regionprops_noalloc.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp]
     L.pseg_vit_tensors.argtypes = [vp, i32, i32, i32, vp, vp]
     L.pseg_disk_mask.argtypes = [vp, i32, vp]
     L.pseg_resize_frames.argtypes = [vp, vp, i32, i32, i32, vp]
@@ -76,7 +84,7 @@ def load():
     L.pseg_last_ms.argtypes = [vp, i32]
     L.pseg_last_ms.restype = C.c_float
     for f in ("pseg_create", "pseg_destroy", "pseg_set_stream", "pseg_bgcorrect", "pseg_detect", "pseg_process", "pseg_process_part", "pseg_process_batches", "pseg_process_batches",
-              "pseg_fetch_crops", "pseg_regionprops", "pseg_vit_tensors", "pseg_disk_mask", "pseg_resize_frames", "pseg_synth_frames"):
+              "pseg_fetch_crops", "pseg_regionprops", "pseg_regionprops_noalloc", "pseg_vit_tensors", "pseg_disk_mask", "pseg_resize_frames", "pseg_synth_frames"):
         getattr(L, f).restype = i32
     _lib = L
     return L

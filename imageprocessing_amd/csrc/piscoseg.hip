@@ -1714,6 +1714,7 @@ __global__ void k_init_sums(long long *sums, int n_saved)
 // host side
 // ------------------------------------------------------------------------------------------------
 static inline unsigned nblocks(size_t n, unsigned bs = 256) { return (unsigned)((n + bs - 1) / bs); }
+static hipError_t rp_static_lookup(int device);              // device address of the no-alloc entry point's scratch array
 
 extern "C" int pseg_create(int device, int H, int W, int max_frames, pseg_ctx **out)
 {
@@ -1729,6 +1730,7 @@ extern "C" int pseg_create(int device, int H, int W, int max_frames, pseg_ctx **
     ctx->device = device; ctx->H = H; ctx->W = W; ctx->WW = W / 64; ctx->maxF = max_frames; ctx->P = (size_t)H * W;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&ctx->stream) != hipSuccess) { delete ctx; return PSEG_ERR_HIP; }
     ctx->own_stream = true;
+    if (rp_static_lookup(device) != hipSuccess) { hipStreamDestroy(ctx->stream); delete ctx; return PSEG_ERR_HIP; }
     if (const char *e = getenv("PSEG_BG_CHUNKS")) ctx->bg_chunks = atoi(e) > 0 ? atoi(e) : 1;
     if (const char *e = getenv("PSEG_BG_GENERIC")) ctx->force_generic = atoi(e) != 0;
     {
@@ -2503,6 +2505,99 @@ extern "C" int pseg_regionprops(pseg_ctx *ctx, const uint8_t *mask, const uint8_
     HIPCHK(hipMemcpyAsync(q, d_sums, sizeof(q), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     if (q[0] == 0) {                                        // empty mask: scikit-image finds no region, the reference would raise
+        for (int k = 0; k < PSEG_NPROPS; k++) props[k] = NAN;
+        return fail(ctx, PSEG_ERR_ARG, "mask has no set pixel");
+    }
+    props_from_sums(q, (double)w, (double)h, props);
+    if (sums_out) memcpy(sums_out, q, sizeof(q));
+    return PSEG_OK;
+}
+
+// ---- pseg_regionprops for callers that cannot allocate ----------------------------------------------------------------
+// Same kernels as pseg_regionprops; the scratch they need (small tables, sums, row extremes, the three crop planes the
+// band kernel writes) lives in one file-scope device array instead of the context's growing buffers.  Every GPU holds its
+// own copy of the array; its device address is looked up once per device in pseg_create (hipGetSymbolAddress) and kept in
+// g_rp_static_ptr -- host code uses that pointer, never the array's name.  All calls on one GPU share the array: the call
+// holds a per-device mutex from its first launch to the end of its copy-back, so calls from several contexts of one process
+// queue up instead of racing (callers in other processes have their own copy of the array).
+#define RP_NA_MAX_PIXELS PSEG_NOALLOC_MAX_PIXELS
+#define RP_NA_MAX_ROWS PSEG_NOALLOC_MAX_ROWS
+#define RP_NA_MAX_BANDS 64
+#define RP_NA_O_GEO 0                                       // int32 [8]
+#define RP_NA_O_LL 64                                       // int64 [6]: crop_off[2] | band_off[2] | row_off[2]
+#define RP_NA_O_BOBJ 128                                    // int32 [RP_NA_MAX_BANDS]
+#define RP_NA_O_SUMS (RP_NA_O_BOBJ + RP_NA_MAX_BANDS * 4)   // int64 [PSEG_NSUMS]
+#define RP_NA_O_EXT (RP_NA_O_SUMS + PSEG_NSUMS * 8)         // int32 [2 * RP_NA_MAX_ROWS]
+#define RP_NA_O_CROPS ((RP_NA_O_EXT + 2 * RP_NA_MAX_ROWS * 4 + 255) & ~255)
+#define RP_NA_BYTES (RP_NA_O_CROPS + 3 * RP_NA_MAX_PIXELS + 256)
+static __device__ __align__(256) unsigned char g_rp_static[RP_NA_BYTES];
+static void *g_rp_static_ptr[PSEG_MAX_DEVICES];             // device address of g_rp_static on each GPU (set in pseg_create)
+static std::mutex g_rp_static_mu[PSEG_MAX_DEVICES];
+static std::mutex g_rp_static_init_mu;
+
+// once per device, with that device current
+static hipError_t rp_static_lookup(int device)
+{
+    if (device < 0 || device >= PSEG_MAX_DEVICES) return hipSuccess;     // such a device simply has no no-alloc entry point
+    std::lock_guard<std::mutex> lk(g_rp_static_init_mu);
+    if (g_rp_static_ptr[device]) return hipSuccess;
+    void *p = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(g_rp_static));
+    if (e == hipSuccess) g_rp_static_ptr[device] = p;
+    return e;
+}
+
+// the small tables of one window, written on the device (no host staging buffer, no copy): geo, offsets, band map, sums
+__global__ void k_rp_setup(unsigned char *d, int w, int h, int nbands)
+{
+    int32_t *g = (int32_t *)(d + RP_NA_O_GEO);
+    long long *ll = (long long *)(d + RP_NA_O_LL);
+    int32_t *bobj = (int32_t *)(d + RP_NA_O_BOBJ);
+    long long *sums = (long long *)(d + RP_NA_O_SUMS);
+    const int t = threadIdx.x;
+    if (t == 0) {
+        g[0] = 0; g[1] = 0; g[2] = 0; g[3] = w; g[4] = h; g[5] = 0; g[6] = (w + 31) >> 5; g[7] = 0;
+        ll[0] = 0; ll[1] = (long long)w * h; ll[2] = 0; ll[3] = nbands; ll[4] = 0; ll[5] = h;
+    }
+    if (t < RP_NA_MAX_BANDS) bobj[t] = 0;                    // every band belongs to object 0
+    if (t < PSEG_NSUMS) sums[t] = t == 6 ? 255 : 0;          // the sums accumulate: they start from zero on every call (min at 255)
+}
+
+extern "C" int pseg_regionprops_noalloc(pseg_ctx *ctx, const uint8_t *mask, const uint8_t *img, int h, int w, int stride,
+                                        double *props, int64_t *sums_out)
+{
+    if (!ctx) return PSEG_ERR_ARG;
+    if (!mask || !img || !props || h < 1 || w < 1 || stride < w) return fail(ctx, PSEG_ERR_ARG, "bad window");
+    if (w > 8192 || h > RP_NA_MAX_ROWS || (long long)w * h > RP_NA_MAX_PIXELS)
+        return fail(ctx, PSEG_ERR_CAPACITY, "pseg_regionprops_noalloc: window beyond the static scratch (at most " +
+                    std::to_string(RP_NA_MAX_ROWS) + " rows, 8192 columns and " + std::to_string(RP_NA_MAX_PIXELS) +
+                    " pixels); use pseg_regionprops");
+    const int rpb = crop_rows_per_band(w), nbands = (h + rpb - 1) / rpb;
+    if (nbands > RP_NA_MAX_BANDS) return fail(ctx, PSEG_ERR_CAPACITY, "pseg_regionprops_noalloc: too many row bands");
+    if (ctx->device < 0 || ctx->device >= PSEG_MAX_DEVICES || !g_rp_static_ptr[ctx->device])
+        return fail(ctx, PSEG_ERR_HIP, "pseg_regionprops_noalloc: no static scratch on this device");
+    HIPCHK(hipSetDevice(ctx->device));
+    std::lock_guard<std::mutex> lk(g_rp_static_mu[ctx->device]);
+    unsigned char *d = (unsigned char *)g_rp_static_ptr[ctx->device];
+    hipStream_t st = ctx->stream;
+    const size_t lds = (size_t)h * HULL_LDS_PER_ROW + 64;    // <= 28.7 KB for RP_NA_MAX_ROWS: inside the default limit
+    SegState S;
+    memset(&S, 0, sizeof(S));
+    S.F = 1; S.H = h; S.W = stride; S.WW = (stride + 63) / 64;
+    long long *d_sums = (long long *)(d + RP_NA_O_SUMS);
+    uint8_t *c0 = d + RP_NA_O_CROPS;
+    hipLaunchKernelGGL(k_rp_setup, dim3(1), dim3(64), 0, st, d, w, h, nbands);
+    hipLaunchKernelGGL(k_crops_sums<true>, dim3(nbands), dim3(CROP_THREADS), 0, st, S, 1, (const int32_t *)(d + RP_NA_O_GEO),
+                       (const long long *)(d + RP_NA_O_LL), (const long long *)(d + RP_NA_O_LL + 16), (const int32_t *)nullptr, img, img,
+                       c0, c0 + (size_t)w * h, c0 + (size_t)2 * w * h, d_sums, (const long long *)(d + RP_NA_O_LL + 32),
+                       (int32_t *)(d + RP_NA_O_EXT), (const int32_t *)(d + RP_NA_O_BOBJ), mask);
+    hipLaunchKernelGGL(k_convex, dim3(1), dim3(128), lds, st, 1, (const int32_t *)(d + RP_NA_O_GEO), (const long long *)(d + RP_NA_O_LL + 32),
+                       (const int32_t *)(d + RP_NA_O_EXT), d_sums, 0, h);
+    HIPCHK(hipGetLastError());
+    int64_t q[PSEG_NSUMS];
+    HIPCHK(hipMemcpyAsync(q, d_sums, sizeof(q), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (q[0] == 0) {
         for (int k = 0; k < PSEG_NPROPS; k++) props[k] = NAN;
         return fail(ctx, PSEG_ERR_ARG, "mask has no set pixel");
     }

@@ -218,17 +218,18 @@ class Segmenter:
         tab = self._table(t, fetch_crops) if want_table else None
         return cleaned, ms, valid, tab
 
-    def regionprops(self, mask, img):
+    def regionprops(self, mask, img, no_alloc=False):
         """calculate_regionprops (detection.py:75) of one window: mask / img are 2-D uint8 CUDA tensors of equal shape
-        (rows may be strided).  Returns float64[32] in PROP_KEYS order."""
+        (rows may be strided).  Returns float64[32] in PROP_KEYS order.  ``no_alloc``: the entry point that works in a
+        static device array (windows up to 1024 rows / 262144 pixels) and allocates nothing."""
         h, w = mask.shape
         if img.shape != mask.shape or mask.stride(1) != 1 or img.stride(1) != 1 or mask.stride(0) != img.stride(0):
             raise PsegError("mask and img must be 2-D uint8 windows of the same shape and row stride")
         import torch
         torch.cuda.current_stream(mask.device).synchronize()
         props = np.zeros(_lib.NPROPS, np.float64)
-        self._chk(self.L.pseg_regionprops(self.h, mask.data_ptr(), img.data_ptr(), int(h), int(w), int(mask.stride(0)),
-                                          props.ctypes.data, None))
+        fn = self.L.pseg_regionprops_noalloc if no_alloc else self.L.pseg_regionprops
+        self._chk(fn(self.h, mask.data_ptr(), img.data_ptr(), int(h), int(w), int(mask.stride(0)), props.ctypes.data, None))
         return props
 
     def vit_tensors(self, first=0, count=None, plane="masked", out=None):

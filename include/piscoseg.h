@@ -135,6 +135,19 @@ int pseg_fetch_crops(pseg_ctx *ctx, uint8_t *raw, uint8_t *masked, uint8_t *mask
 int pseg_regionprops(pseg_ctx *ctx, const uint8_t *mask, const uint8_t *img, int h, int w, int stride,
                      double *props, int64_t *sums_out);
 
+/* pseg_regionprops for callers that cannot allocate.  NO COUNTERPART IN THE REFERENCE: it exists for callers that must not
+ * reach hipMalloc / hipFree -- code under HIP graph capture, tight serving loops, harnesses that forbid allocation.  Same
+ * arguments, same kernels and bit-identical results as pseg_regionprops; the scratch (tables, sums, row extremes and the
+ * three crop planes the band kernel writes) is a file-scope device array of about 0.8 MB that every GPU the library runs on
+ * holds until the process ends, so the window is limited: h <= PSEG_NOALLOC_MAX_ROWS, w <= 8192 and
+ * w * h <= PSEG_NOALLOC_MAX_PIXELS (PSEG_ERR_CAPACITY beyond that).  The call allocates nothing, on the device or through
+ * the runtime.  All calls on one GPU share the array: calls made through this library in one process are serialised by a
+ * per-device lock; anything else that overlaps them on the same array would race. */
+#define PSEG_NOALLOC_MAX_PIXELS 262144
+#define PSEG_NOALLOC_MAX_ROWS 1024
+int pseg_regionprops_noalloc(pseg_ctx *ctx, const uint8_t *mask, const uint8_t *img, int h, int w, int stride,
+                             double *props, int64_t *sums_out);
+
 /* SURVEY.md 8(f) N3 -- classifier inputs of saved objects [first, first+count) of the context's last detection, read from
  * the packed device crops (plane 0 = raw, 1 = masked: the Deconv_crops/ images the classifier is pointed at, 2 = mask).
  * Replaces, for crops that never left the GPU, Image.open(...).convert('RGB') + get_pad_transform's ResizeAndPad((224, 224))
