@@ -1,16 +1,22 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path (BASELINE.json): frames/s on 2560x2560 uint8 PISCO-like stacks.
 
-One "step" = one pass of the fused hot path (background correction -> threshold -> external
-objects -> area/bbox/label map -> crops + property sums) over one reference batch of 200 frames
-(segmenter.py:209) already resident in HBM.  The N=1 workload is BASELINE.json configs[1]: a
-2000-frame stack (10 batches), ~50 objects/frame.  With N>1 every rank runs its own 10 batches
-(weak scaling; batches are independent in the reference) and the object tables are gathered to
-rank 0 over RCCL inside the timed region.
+One "step" = one pass of the fused hot path (background correction -> threshold -> external objects -> area / bbox /
+label map -> crops + property sums) over the whole stack of the configuration, resident in HBM:
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel group, timed with HIP events
-on the library's stream; `cpu_baseline` is the CPU oracle (a port of the reference's arithmetic) on
-one batch of the same frames, run with the reference's process topology on the host cores of this box.
+  N = 1   BASELINE.json configs[1]: a 2000-frame stack = 10 reference batches of 200 frames (segmenter.py:209), ~50
+          objects per frame (--workload uvp5_dense / uvp5_dense_saved: configs[3], ~2000 particles per frame).
+  N > 1   configs[2]: a 10 000-frame stack cut into contiguous frame ranges (sharding.plan_ranges): every rank holds its
+          range plus the forward halos of background-window frames, runs pseg_process_part on its parts, and the object
+          tables are gathered to rank 0 over RCCL inside the timed region.  The total work is fixed: "scaling": "strong".
+          --scaling weak: every rank runs its own 2000-frame stack (whole batches, no halo).
+
+A single caller thread keeps --streams contexts in flight with pseg_submit / pseg_wait (--driver threads: one host thread
+per context, the round-1 form).
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel group, timed with HIP events on the library's stream
+during the timed region; `roofline_groups` has every group; `cpu_baseline` is the CPU oracle (a port of the reference's
+arithmetic) on BASELINE.json configs[0] (100 frames, seed 1) with the reference's process topology on this box's cores.
 """
 import argparse
 import json
@@ -26,39 +32,48 @@ sys.path.insert(0, ROOT)
 H = W = 2560
 P = H * W
 BATCH = 200
-GATHER_EVERY = 4                           # batches per table gather (N > 1)
+GATHER_EVERY = 4                           # library calls per table gather (N > 1)
 HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: 8.0 TB/s spec peak
 PATH_BYTES_PER_FRAME = 6 * P               # raw read + cleaned write + int32 label write
-# algorithmic HBM bytes per frame of each kernel group (DESIGN.md "Kernels and rooflines")
-GROUP_BYTES = {
-    "bg_correct": 2 * P + P // 8,          # read raw once, write cleaned once, write the 1-bit plane
-    "label_map": 4 * P,                    # int32 label map written once
-}
 GROUP_NAMES = {0: "bg_correct", 2: "sparse_labelling", 3: "label_map", 4: "crops_props"}
+
+
+def group_bytes_per_frame(name, rows_pf, crop_bytes_pf, labels_on):
+    """algorithmic HBM bytes per frame of a kernel group"""
+    if name == "bg_correct":
+        return 2 * P + P // 8              # raw read once, cleaned written once, the 1-bit threshold plane written
+    if name == "label_map":
+        return 4 * P if labels_on else 0   # int32 label map written once
+    if name == "sparse_labelling":
+        return P // 8                      # the threshold plane read once
+    return 4 * crop_bytes_pf + 44 * 8 * rows_pf      # crops: one read + three planes written; the rows of the table
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--batches", type=int, default=10, help="distinct 200-frame batches resident per rank")
-    ap.add_argument("--workload", default="pisco", choices=["pisco", "uvp5_dense"])
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=0, help="frames of the stack (default: 2000 at N = 1 / weak, 10000 strong)")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"], help="N > 1 only")
+    ap.add_argument("--workload", default="pisco", choices=["pisco", "uvp5_dense", "uvp5_dense_saved"])
     ap.add_argument("--no-labels", action="store_true", help="streamed mode: label map not materialised (config #5)")
-    ap.add_argument("--cpu-frames", type=int, default=200, help="frames of the CPU-baseline sample (0 = skip); 200 = one reference batch")
+    ap.add_argument("--cpu", default="writes", choices=["on", "off", "writes"], help="CPU baseline: on = configs[0] without file "
+                    "writes; writes = also with PNG / CSV writes; off = skip")
+    ap.add_argument("--cpu-frames", type=int, default=100, help="frames of the CPU-baseline sample (configs[0]: 100)")
     ap.add_argument("--cpu-procs", default="3,8", help="background-correction,detection processes of the CPU baseline "
                     "(reference topology: bg_correction.py:120 / segmenter.py:252); '1,1' = single core, in-process")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo + --single-device rehearses the N > 1 path on one GPU")
     ap.add_argument("--single-device", action="store_true", help="every rank uses cuda:0 (rehearsal only; never a measurement)")
-    ap.add_argument("--streams", type=int, default=3, help="contexts (own HIP stream + host thread each) that alternate batches")
-    ap.add_argument("--batches-per-call", type=int, default=1, help="consecutive reference batches handed to the library in one call "
-                    "(pseg_process_batches: every batch keeps its own background window; a step stays one batch of 200 frames)")
+    ap.add_argument("--streams", type=int, default=3, help="contexts (own HIP stream each) that alternate library calls")
+    ap.add_argument("--driver", default="submit", choices=["submit", "threads"])
+    ap.add_argument("--host-batches", type=int, default=6, help="batches of the host-input measurement (0 = skip)")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     from imageprocessing_amd import sharding, synth
-    from imageprocessing_amd.engine import Segmenter
+    from imageprocessing_amd.engine import HostPipeline, Segmenter
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -80,79 +95,133 @@ def main():
     dev = f"cuda:{local_rank}"
     cdev = dev if args.backend == "nccl" else "cpu"        # where the collectives' tensors live
 
-    import queue
-    import threading
+    strong = world > 1 and args.scaling == "strong"
+    total_frames = args.frames or (10000 if strong else 2000)
+    cfg = synth.CONFIGS[args.workload]
     ns = max(1, args.streams)
-    bpc = max(1, args.batches_per_call)                      # batches per library call
-    segs = [Segmenter(H, W, max_frames=BATCH * bpc, device=local_rank) for _ in range(ns)]
+    labels_on = not args.no_labels
+
+    # ---- the rank's frames and its library calls (start, n_emit, n_avail): whole batches, or parts with forward halos ----
+    if strong:
+        seed = 3
+        parts = sharding.plan_ranges(total_frames, world)[rank]
+        g0 = parts[0]["start"] if parts else 0
+        g1 = max((p["start"] + p["n_avail"] for p in parts), default=0)
+        calls = [(p["start"] - g0, p["n_emit"], p["n_avail"], p["start"]) for p in parts]
+    else:
+        seed = 2 + 1000 * rank
+        g0, g1 = 0, total_frames
+        calls = [(a, m, m, a + rank * total_frames) for a, m in sharding.batches_of(total_frames, BATCH)]
+    max_call = max((c[2] for c in calls), default=1)
+    segs = [Segmenter(H, W, max_frames=max(max_call, BATCH), device=local_rank) for _ in range(ns)]
     seg = segs[0]
     mask = seg.disk_mask(1200)
-    cfg = synth.CONFIGS[args.workload]
-    nb = max(1, min(args.batches, args.steps + args.warmup))
-    nb = ((nb + bpc - 1) // bpc) * bpc                       # whole groups of batches
-    seed = 2 + 1000 * rank
-    stacks = []                                              # nb / bpc resident groups of bpc consecutive batches each
-    for g in range(nb // bpc):
-        objs, off = synth.make_objects(BATCH * bpc, H, W, seed, frame0=g * bpc * BATCH, **cfg)
-        stacks.append(seg.synth_frames(BATCH * bpc, seed, objs, off, frame0=g * bpc * BATCH))
-    cleaned = [torch.empty((BATCH * bpc, H, W), dtype=torch.uint8, device=dev) for _ in range(ns)]
-    labels = [None if args.no_labels else torch.empty((BATCH * bpc, H, W), dtype=torch.int32, device=dev) for _ in range(ns)]
+    stack = torch.empty((max(g1 - g0, 1), H, W), dtype=torch.uint8, device=dev)
+    for a in range(0, g1 - g0, BATCH):                       # rendered on the device, 200 frames at a time
+        m = min(BATCH, g1 - g0 - a)
+        objs, off = synth.make_objects(m, H, W, seed, frame0=g0 + a, **cfg)
+        seg.synth_frames(m, seed, objs, off, frame0=g0 + a, out=stack[a:a + m])
+    cleaned = [torch.empty((max_call, H, W), dtype=torch.uint8, device=dev) for _ in range(ns)]
+    labels = [torch.empty((max_call, H, W), dtype=torch.int32, device=dev) if labels_on else None for _ in range(ns)]
+    emitted = sum(c[1] for c in calls)
+    loaded = sum(c[2] for c in calls)
 
     gatherer = sharding.TableGatherer(device=cdev) if world > 1 else None
     wire = np.empty(256 << 20, np.uint8) if world > 1 else None     # reused by pack_table
     group_ms = {k: 0.0 for k in GROUP_NAMES}
-    stats = dict(rows=0, saved=0, crop_bytes=0, contours=0, gather_s=0.0)
-    lock = threading.Lock()
+    stats = dict(rows=0, saved=0, crop_bytes=0, contours=0, gather_s=0.0, calls=0, frames=0)
 
-    def call(c, nbat, k, timed, out_q=None):
-        """library call number c: nbat consecutive batches (steps) through the fused hot path on context k"""
-        grp = stacks[c % len(stacks)]
-        m = nbat * BATCH
-        _, _, _, tab = segs[k].process(grp[:m], mask=mask, cleaned=cleaned[k][:m], labels=None if labels[k] is None else labels[k][:m],
-                                       batch_len=BATCH)
-        if out_q is not None:
-            out_q.put((c, tab))                              # packed and gathered by the main thread
+    def kwargs(c, k):
+        a, ne, na, _ = calls[c]
+        return dict(mask=mask, cleaned=cleaned[k][:ne], labels=None if labels[k] is None else labels[k][:ne],
+                    n_emit=None if ne == na else ne)
+
+    def account(c, k, tab, timed):
         if timed:
-            with lock:
-                stats["rows"] += tab.n_rows
-                stats["saved"] += int(tab.saved.sum())
-                stats["crop_bytes"] += tab.crop_bytes
-                stats["contours"] += int(tab.frame_n_contours.sum())
+            stats["rows"] += tab.n_rows
+            stats["saved"] += len(tab.saved_row)
+            stats["crop_bytes"] += tab.crop_bytes
+            stats["contours"] += int(tab.frame_n_contours.sum())
+            stats["calls"] += 1
+            stats["frames"] += calls[c][1]
+            for g in GROUP_NAMES:
+                group_ms[g] += segs[k].last_ms(g)
 
-    def run(count, timed):
-        """count steps (batches) as calls of bpc batches (the last call takes the remainder), dealt round-robin to the
-        contexts (one host thread each); the object tables are gathered to rank 0 from the main thread, in call order,
-        while later batches compute"""
-        calls = [(c, min(bpc, count - c * bpc)) for c in range((count + bpc - 1) // bpc)]
-        out_q = queue.Queue() if world > 1 else None
-        ths = [threading.Thread(target=lambda k=k: [call(c, nbat, k, timed, out_q) for c, nbat in calls[k::ns]]) for k in range(ns)]
-        for t in ths:
-            t.start()
-        if world > 1:
-            # tables of about GATHER_EVERY consecutive batches travel in one message: fewer, larger collectives
-            pending, fill, since = {}, 0, 0
-            for want, nbat in calls:
+    class Gather:
+        """tables of GATHER_EVERY consecutive calls travel in one message: fewer, larger collectives"""
+        def __init__(self):
+            self.fill, self.since = 0, 0
+
+        def add(self, c, tab, last, timed):
+            if world == 1:
+                return
+            t0 = time.perf_counter()
+            blob = sharding.pack_table(tab, frame_base=calls[c][3], out=wire[self.fill:])
+            self.fill += blob.size
+            self.since += 1
+            if self.since >= GATHER_EVERY or last:
+                gatherer.gather(wire[:self.fill])
+                self.fill, self.since = 0, 0
+            if timed:
+                stats["gather_s"] += time.perf_counter() - t0
+
+    def one_pass(timed):
+        """every call of this rank once (= one step), pipelined over the contexts"""
+        gat = Gather()
+        nc = len(calls)
+        if args.driver == "submit":
+            inflight = []
+            for c in range(nc):
+                k = c % ns
+                if len(inflight) == ns:
+                    c0, k0 = inflight.pop(0)
+                    tab = segs[k0].wait()[3]
+                    account(c0, k0, tab, timed)
+                    gat.add(c0, tab, False, timed)
+                a, ne, na, _ = calls[c]
+                segs[k].submit(stack[a:a + na], **kwargs(c, k))
+                inflight.append((c, k))
+            for i, (c0, k0) in enumerate(inflight):
+                tab = segs[k0].wait()[3]
+                account(c0, k0, tab, timed)
+                gat.add(c0, tab, i == len(inflight) - 1, timed)
+        else:
+            import queue
+            import threading
+            out_q = queue.Queue()
+
+            def work(k):
+                for c in range(k, nc, ns):
+                    a, ne, na, _ = calls[c]
+                    tab = segs[k].process(stack[a:a + na], **kwargs(c, k))[3]
+                    ms = {g: segs[k].last_ms(g) for g in GROUP_NAMES}
+                    out_q.put((c, k, tab, ms))
+            ths = [threading.Thread(target=work, args=(k,)) for k in range(ns)]
+            for t in ths:
+                t.start()
+            pending = {}
+            for want in range(nc):
                 while want not in pending:
-                    c, tab = out_q.get()
-                    pending[c] = tab
-                g0 = time.perf_counter()
-                blob = sharding.pack_table(pending.pop(want), frame_base=(rank * nb + (want * bpc) % nb) * BATCH, out=wire[fill:])
-                fill += blob.size
-                since += nbat
-                if since >= GATHER_EVERY or want == calls[-1][0]:
-                    gatherer.gather(wire[:fill])
-                    fill, since = 0, 0
+                    c, k, tab, ms = out_q.get()
+                    pending[c] = (k, tab, ms)
+                k, tab, ms = pending.pop(want)
                 if timed:
-                    stats["gather_s"] += time.perf_counter() - g0
-        for t in ths:
-            t.join()
+                    stats["rows"] += tab.n_rows; stats["saved"] += len(tab.saved_row); stats["crop_bytes"] += tab.crop_bytes
+                    stats["contours"] += int(tab.frame_n_contours.sum()); stats["calls"] += 1; stats["frames"] += calls[want][1]
+                    for g in GROUP_NAMES:
+                        group_ms[g] += ms[g]
+                gat.add(want, tab, want == nc - 1, timed)
+            for t in ths:
+                t.join()
 
-    run(args.warmup, False)
+    for _ in range(args.warmup):
+        one_pass(False)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    run(args.steps, True)
+    for _ in range(args.steps):
+        one_pass(True)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -161,64 +230,121 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    # kernel-group durations for the roofline: HIP events on the library's stream, one context alone on the GPU
-    # (with several contexts in flight the kernels of different batches overlap and share the bandwidth)
-    nprobe = 3
-    for i in range(nprobe):
-        call(i, bpc, 0, False)
-        for k in GROUP_NAMES:
-            group_ms[k] += seg.last_ms(k)
 
-    frames = args.steps * BATCH * world
+    # ---- after the timed region: what was timed is checked, and the groups are timed once more with the GPU to themselves ----
+    checked = None
+    iso_ms = {k: 0.0 for k in GROUP_NAMES}
+    if calls:
+        # the first call of this rank on every context at once against a single context with the device to itself
+        a, ne, na, _ = calls[0]
+        want_c = torch.empty((ne, H, W), dtype=torch.uint8, device=dev)
+        want_l = torch.empty((ne, H, W), dtype=torch.int32, device=dev) if labels_on else None
+        _, ms0, v0, t0_ = segs[0].process(stack[a:a + na], mask=mask, cleaned=want_c, labels=want_l, n_emit=None if ne == na else ne)
+        for k in GROUP_NAMES:
+            iso_ms[k] = segs[0].last_ms(k)
+        ref = {f: np.array(getattr(t0_, f)) for f in ("frame_row_offset", "frame_n_contours", "frame_mean", "frame_std", "c", "label",
+                                                      "area", "x", "y", "w", "h", "saved", "saved_props", "crop_offset")}
+        for k in range(ns):
+            segs[k].submit(stack[a:a + na], **kwargs(0, k))
+        checked = True
+        okv = torch.from_numpy(v0.astype(bool)).to(dev)
+        for k in range(ns):
+            c_, ms_, v_, t_ = segs[k].wait()
+            same = torch.equal(c_[okv], want_c[okv]) and np.array_equal(ms_, ms0) and np.array_equal(v_, v0)
+            same = same and (not labels_on or torch.equal(labels[k][:ne], want_l))
+            same = same and all(np.array_equal(getattr(t_, f), ref[f], equal_nan=True) for f in ref)
+            checked = checked and bool(same)
+        del want_c, want_l
+        if not checked:
+            raise SystemExit("bench: the contexts' results differ from the single-context run")
+
+    frames = args.steps * (total_frames if strong else total_frames * world)
     fps = frames / elapsed
-    # dominant kernel group by device time (HIP events inside the library, on its own stream)
-    dom = max(GROUP_NAMES, key=lambda k: group_ms[k])
-    dom_name = GROUP_NAMES[dom]
-    dom_ms = group_ms[dom] / nprobe
-    traffic = None
+    ncalls = max(stats["calls"], 1)
+    fr = max(stats["frames"], 1)
+    rows_pf, crop_pf = stats["rows"] / fr, stats["crop_bytes"] / fr
+    obj_bytes = 3 * crop_pf + 44 * 8 * rows_pf               # three crop planes + 44 x 8 B per row, per frame
+    frames_per_call = fr / ncalls
+    traffic = {}
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get(dom_name)    # PMC bytes of a 200-frame launch (profiles/README.md)
-            traffic = traffic * bpc if traffic is not None else None      # a launch covers bpc batches; bytes are per frame
+            traffic = json.load(open(tpath))                  # PMC bytes of a 200-frame launch (profiles/README.md)
         except Exception:
-            traffic = None
-    if dom_name in GROUP_BYTES:
-        launch_bytes = GROUP_BYTES[dom_name] * BATCH * bpc
-    else:   # sparse groups: their share of the path's compulsory bytes is the object payload only
-        launch_bytes = (stats["crop_bytes"] * 3 + stats["rows"] * 44 * 8) / max(args.steps, 1) * bpc
-    achieved = launch_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-    obj_bytes = (stats["crop_bytes"] * 3 + stats["rows"] * 44 * 8) / max(args.steps * BATCH, 1)     # rank 0's batches
+            traffic = {}
+    groups = {}
+    for k, name in GROUP_NAMES.items():
+        ms = group_ms[k] / ncalls                            # average launch (group) duration over the timed region
+        b = group_bytes_per_frame(name, rows_pf, crop_pf, labels_on) * frames_per_call
+        ach = b / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        tr = traffic.get(name) if args.workload == "pisco" else None
+        groups[name] = {"avg_ms": round(ms, 4), "avg_ms_alone": round(iso_ms[k], 4), "algorithmic_bytes": int(b),
+                        "achieved_GBps": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4),
+                        "counter_bytes": None if tr is None else int(tr * frames_per_call / BATCH),
+                        "counter_over_algorithmic": None if (tr is None or b == 0) else round(tr * frames_per_call / BATCH / b, 3)}
+    dom_name = max(groups, key=lambda g: groups[g]["avg_ms"])
+    dom = groups[dom_name]
+    path_bytes = PATH_BYTES_PER_FRAME if labels_on else 2 * P
+    halo = (loaded - emitted) / max(emitted, 1)
+    if strong:
+        wl = (f"configs[2]: {total_frames}-frame {args.workload} stack frame-sharded over {world} GPUs (plan_ranges: "
+              f"{emitted} frames + {loaded - emitted} halo frames on rank 0), RCCL gather of object tables")
+    else:
+        idx = 1 if args.workload == "pisco" else 3
+        wl = (f"configs[{idx}]: {total_frames}-frame {args.workload} stack{' per GPU' if world > 1 else ''}, batches of {BATCH}")
     out = {
         "metric": "frames/sec (2560x2560 uint8), hot path bg_correction+detection",
         "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "config": {"workload": f"configs[1]: {nb * BATCH}-frame {args.workload} stack per GPU, batches of {BATCH}, bg window 12, "
-                               f"~{cfg['per_frame']} objects/frame, label map {'off' if args.no_labels else 'on'}, {bpc} batches per library call",
-                   "frames_per_step": BATCH, "objects_per_frame": round(stats["contours"] / (args.steps * BATCH), 1),
-                   "rows_per_frame": round(stats["rows"] / (args.steps * BATCH), 1),
-                   "saved_per_frame": round(stats["saved"] / (args.steps * BATCH), 1)},
-        "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                     "avg_launch_ms": round(dom_ms, 4), "bytes_per_launch": int(launch_bytes)},
-        "path": {"bytes_per_frame": PATH_BYTES_PER_FRAME if not args.no_labels else 2 * P,
-                 # compulsory bytes = the frame terms + the measured object payload (three crop planes, 44 x 8 B per row)
-                 "object_bytes_per_frame": round(obj_bytes, 1),
-                 "frac_of_hbm_peak_per_gpu_with_objects": round(fps / world * ((PATH_BYTES_PER_FRAME if not args.no_labels else 2 * P) + obj_bytes)
-                                                                / (HBM_PEAK_GBS * 1e9), 4),
-                 "frac_of_hbm_peak_per_gpu": round(fps / world * (PATH_BYTES_PER_FRAME if not args.no_labels else 2 * P) / (HBM_PEAK_GBS * 1e9), 4),
-                 "contexts": ns, "table_gather_ms_per_step_rank0": round(stats["gather_s"] / args.steps * 1e3, 3) if world > 1 else None,
-                 "batches_per_call": bpc,
-                 "group_ms_per_step_single_context": {GROUP_NAMES[k]: round(group_ms[k] / nprobe / bpc, 3) for k in GROUP_NAMES}},
+        "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 3), "higher_is_better": True,
+        "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": wl + f", bg window 12, ~{cfg['per_frame']} objects/frame, label map {'on' if labels_on else 'off'}",
+                   "frames_per_step": total_frames if strong else total_frames * world,
+                   "library_calls_per_step_rank0": len(calls), "objects_per_frame": round(stats["contours"] / fr, 1),
+                   "rows_per_frame": round(rows_pf, 1), "saved_per_frame": round(stats["saved"] / fr, 1)},
+        "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": dom["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": dom["frac"], "traffic": dom["counter_bytes"], "avg_launch_ms": dom["avg_ms"],
+                     "bytes_per_launch": dom["algorithmic_bytes"], "frames_per_launch": round(frames_per_call, 1)},
+        "roofline_groups": groups,
+        "path": {"bytes_per_frame": path_bytes, "object_bytes_per_frame": round(obj_bytes, 1),
+                 "frac_of_hbm_peak_per_gpu": round(fps / world * path_bytes / (HBM_PEAK_GBS * 1e9), 4),
+                 "frac_of_hbm_peak_per_gpu_with_objects": round(fps / world * (path_bytes + obj_bytes) / (HBM_PEAK_GBS * 1e9), 4),
+                 "contexts": ns, "driver": args.driver, "results_checked_after_timed_region": checked,
+                 "ranks_seen": dist.get_world_size() if world > 1 else 1,
+                 "halo_overhead": round(halo, 4) if strong else 0.0,
+                 "table_gather_ms_per_step_rank0": round(stats["gather_s"] / max(args.steps, 1) * 1e3, 3) if world > 1 else None},
     }
 
-    if rank == 0 and world == 1 and args.cpu_frames >= 12:
-        # the oracle is the timed CPU port here, never the product path
-        nf = min(args.cpu_frames, BATCH)
-        sample = stacks[0][:nf].cpu().numpy()                # nf <= BATCH: inside the first batch
+    if rank == 0 and world == 1 and args.host_batches > 0:
+        # the same path with the frames starting in (page-locked) host memory and the table + crops ending there: PCIe-bound,
+        # reported beside `value`, never as it
+        nbh = args.host_batches
+        pipe = HostPipeline(H, W, max_frames=BATCH, device=local_rank, depth=2, labels=False)
+        try:
+            for k in range(2):
+                pipe.host[k].copy_(stack[k * BATCH:(k + 1) * BATCH])
+            torch.cuda.synchronize()
+            for _ in pipe.run(((BATCH, None) for _ in range(2)), mask=mask):
+                pass
+            h0 = time.perf_counter()
+            got = 0
+            for b, c_, ms_, v_, tab in pipe.run(((BATCH, None) for _ in range(nbh)), mask=mask):
+                got += tab.n_frames
+            ht = time.perf_counter() - h0
+            out["path"]["host_input_fps"] = round(got / ht, 1)
+            out["path"]["host_input_note"] = (f"{nbh} batches of {BATCH} frames from page-locked host memory: upload, fused path, table and three "
+                                              "crop planes back into page-locked memory, two contexts, one caller thread (label map not "
+                                              "materialised)")
+        finally:
+            pipe.close()
+
+    if rank == 0 and world == 1 and args.cpu != "off" and args.cpu_frames >= 12:
+        # the oracle is the timed CPU port here, never the product path.  BASELINE.json configs[0]: 100 frames, seed 1
+        nf = args.cpu_frames
+        objs, off = synth.make_objects(nf, H, W, 1, **synth.CONFIGS["pisco"])
+        sample = seg.synth_frames(nf, 1, objs, off).cpu().numpy()
         hmask = mask.cpu().numpy()
         pb, pd = (int(v) for v in args.cpu_procs.split(","))
+        extra = {}
         if pb == 1 and pd == 1:
             from tests import helpers
             c0 = time.perf_counter()
@@ -229,13 +355,22 @@ def main():
         else:
             from oracle import cpu_pool
             r = cpu_pool.run(sample, hmask, pb, pd)
-            ct = r["seconds_bg"] + r["seconds_det"]
-            cores = max(pb, pd)
-            how = (f"reference topology: background correction in {pb} processes ({r['seconds_bg']:.2f} s), then detection in "
-                   f"{pd} processes ({r['seconds_det']:.2f} s), frames through /dev/shm")
+            ct = r["seconds"]
+            cores = pb + pd
+            how = (f"reference topology: {pb} background-correction processes feeding {pd} detection processes through a queue of 10, "
+                   f"both pools running at once ({ct:.2f} s; background pool done after {r['seconds_bg']:.2f} s), frames through /dev/shm")
+            if args.cpu == "writes":
+                import shutil
+                import tempfile
+                wd = tempfile.mkdtemp(prefix="pseg_cpu_out_")
+                try:
+                    rw = cpu_pool.run(sample, hmask, pb, pd, write_dir=wd)
+                    extra = {"value_with_png_csv_writes": round(nf / rw["seconds"], 3)}
+                finally:
+                    shutil.rmtree(wd, ignore_errors=True)
         out["cpu_baseline"] = {"value": round(nf / ct, 3), "unit": "frames/s", "cores": cores, "kind": "port",
-                               "sample": f"first {nf} frames of batch 0 as one batch (window 12), NumPy + C oracle, {how}, "
-                                         f"no PNG/CSV writes, host has {os.cpu_count()} logical CPUs"}
+                               "sample": f"configs[0]: {nf} frames, seed 1, one batch (window 12), NumPy + C oracle, {how}, "
+                                         f"no PNG/CSV writes, host has {os.cpu_count()} logical CPUs", **extra}
     if world > 1:
         dist.barrier()
     sys.stdout.flush()

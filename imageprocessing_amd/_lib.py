@@ -12,7 +12,7 @@ NSUMS = 24
 
 SYMBOLS = [
     "pseg_create", "pseg_destroy", "pseg_last_error", "pseg_set_stream", "pseg_bgcorrect", "pseg_detect",
-    "pseg_process", "pseg_process_part", "pseg_process_batches", "pseg_fetch_crops", "pseg_regionprops", "pseg_regionprops_noalloc", "pseg_vit_tensors",
+    "pseg_process", "pseg_process_part", "pseg_process_batches", "pseg_submit", "pseg_wait", "pseg_fetch_crops", "pseg_regionprops", "pseg_regionprops_noalloc", "pseg_vit_tensors",
     "pseg_disk_mask", "pseg_resize_frames", "pseg_synth_frames", "pseg_last_ms",
 ]
 
@@ -74,6 +74,8 @@ def load():
     L.pseg_process.argtypes = [vp, vp, i32, i32, vp, i32, dbl, dbl, vp, vp, vp, vp, C.POINTER(Table)]
     L.pseg_process_part.argtypes = [vp, vp, i32, i32, i32, vp, i32, dbl, dbl, vp, vp, vp, vp, C.POINTER(Table)]
     L.pseg_process_batches.argtypes = [vp, vp, i32, i32, i32, vp, i32, dbl, dbl, vp, vp, vp, vp, C.POINTER(Table)]
+    L.pseg_submit.argtypes = [vp, vp, i32, i32, i32, i32, vp, i32, dbl, dbl, vp, vp, vp, vp]
+    L.pseg_wait.argtypes = [vp, C.POINTER(Table)]
     L.pseg_fetch_crops.argtypes = [vp, vp, vp, vp]
     L.pseg_regionprops.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp]
     L.pseg_regionprops_noalloc.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp]
@@ -83,7 +85,7 @@ def load():
     L.pseg_synth_frames.argtypes = [vp, i32, i32, C.c_uint64, vp, vp, vp]
     L.pseg_last_ms.argtypes = [vp, i32]
     L.pseg_last_ms.restype = C.c_float
-    for f in ("pseg_create", "pseg_destroy", "pseg_set_stream", "pseg_bgcorrect", "pseg_detect", "pseg_process", "pseg_process_part", "pseg_process_batches", "pseg_process_batches",
+    for f in ("pseg_create", "pseg_destroy", "pseg_set_stream", "pseg_bgcorrect", "pseg_detect", "pseg_process", "pseg_process_part", "pseg_process_batches", "pseg_submit", "pseg_wait",
               "pseg_fetch_crops", "pseg_regionprops", "pseg_regionprops_noalloc", "pseg_vit_tensors", "pseg_disk_mask", "pseg_resize_frames", "pseg_synth_frames"):
         getattr(L, f).restype = i32
     _lib = L

@@ -19,6 +19,8 @@
 #include <string>
 #include <vector>
 #include <mutex>
+#include <condition_variable>
+#include <thread>
 
 #include "../../include/piscoseg.h"
 #include "pseg_core.h"
@@ -87,6 +89,7 @@ struct pseg_ctx {
     int n_saved = 0;
     // host views of the last table (page-locked tail buffer): rows [10][t_hr], saved_row, crop_off
     const int32_t *t_rows = nullptr, *t_saved_row = nullptr; const int64_t *t_crop_off = nullptr; size_t t_hr = 1;
+    struct AsyncWorker *worker = nullptr;   // pseg_submit / pseg_wait: the context's own host thread (started on first use)
 };
 
 static int fail(pseg_ctx *c, int code, const std::string &msg)
@@ -1715,6 +1718,7 @@ __global__ void k_init_sums(long long *sums, int n_saved)
 // ------------------------------------------------------------------------------------------------
 static inline unsigned nblocks(size_t n, unsigned bs = 256) { return (unsigned)((n + bs - 1) / bs); }
 static hipError_t rp_static_lookup(int device);              // device address of the no-alloc entry point's scratch array
+static void async_stop(pseg_ctx *ctx);                       // ends the context's worker thread (pseg_submit / pseg_wait)
 
 extern "C" int pseg_create(int device, int H, int W, int max_frames, pseg_ctx **out)
 {
@@ -1750,6 +1754,7 @@ extern "C" int pseg_create(int device, int H, int W, int max_frames, pseg_ctx **
 extern "C" int pseg_destroy(pseg_ctx *ctx)
 {
     if (!ctx) return PSEG_ERR_ARG;
+    async_stop(ctx);
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->bits, &ctx->partials, &ctx->maskpart, &ctx->head, &ctx->outpack, &ctx->rowspans, &ctx->rowcnt,
@@ -2346,6 +2351,82 @@ extern "C" int pseg_process_batches(pseg_ctx *ctx, const uint8_t *frames, int n,
     if (batch_len < 1) return ctx ? fail(ctx, PSEG_ERR_ARG, "batch_len must be positive") : PSEG_ERR_ARG;
     return process_impl(ctx, frames, n, n, batch_len, n_bg_imgs, mask, threshold, min_area_to_segment, min_area_to_save, cleaned,
                         mean_std, valid, labels, out);
+}
+
+// ---- asynchronous form: pseg_submit / pseg_wait ---------------------------------------------------------------------------
+// One call of the fused path makes three short host round trips (run count, table sizes, results) and ends with the float64
+// epilogue of the table.  A caller that wants the GPU busy meanwhile had to bring one host thread per context.  Here every
+// context owns a worker thread inside the library: pseg_submit hands it the arguments and returns at once, pseg_wait blocks
+// until the call has finished and delivers its table.  One caller thread can so keep several contexts in flight
+// (submit A, submit B, wait A, submit A, wait B, ...); on the device the contexts take turns exactly as with caller threads.
+struct AsyncWorker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    bool have_job = false, done = false, quit = false;
+    int rc = 0;
+    pseg_table table;
+    struct { const uint8_t *frames; int n_avail, n_emit, batch_len, n_bg_imgs; const uint8_t *mask; int threshold; double min_seg, min_save;
+             uint8_t *cleaned; double *mean_std; uint8_t *valid; int32_t *labels; } a;
+};
+static void async_main(pseg_ctx *ctx)
+{
+    AsyncWorker *w = ctx->worker;
+    std::unique_lock<std::mutex> lk(w->mu);
+    for (;;) {
+        w->cv.wait(lk, [&] { return w->have_job || w->quit; });
+        if (w->quit) return;
+        auto a = w->a;
+        lk.unlock();
+        const int rc = process_impl(ctx, a.frames, a.n_avail, a.n_emit, a.batch_len, a.n_bg_imgs, a.mask, a.threshold, a.min_seg, a.min_save,
+                                    a.cleaned, a.mean_std, a.valid, a.labels, &w->table);
+        lk.lock();
+        w->rc = rc; w->have_job = false; w->done = true;
+        w->cv.notify_all();
+    }
+}
+extern "C" int pseg_submit(pseg_ctx *ctx, const uint8_t *frames, int n_avail, int n_emit, int batch_len, int n_bg_imgs, const uint8_t *mask,
+                           int threshold, double min_area_to_segment, double min_area_to_save, uint8_t *cleaned, double *mean_std,
+                           uint8_t *valid, int32_t *labels)
+{
+    if (!ctx) return PSEG_ERR_ARG;
+    if (!ctx->worker) {
+        ctx->worker = new AsyncWorker();
+        ctx->worker->th = std::thread(async_main, ctx);
+    }
+    AsyncWorker *w = ctx->worker;
+    std::lock_guard<std::mutex> lk(w->mu);
+    if (w->have_job || w->done) return fail(ctx, PSEG_ERR_ARG, "pseg_submit: the previous submission has not been waited for");
+    w->a = {frames, n_avail, n_emit, batch_len, n_bg_imgs, mask, threshold, min_area_to_segment, min_area_to_save, cleaned, mean_std, valid, labels};
+    w->have_job = true;
+    w->cv.notify_all();
+    return PSEG_OK;
+}
+extern "C" int pseg_wait(pseg_ctx *ctx, pseg_table *out)
+{
+    if (!ctx) return PSEG_ERR_ARG;
+    AsyncWorker *w = ctx->worker;
+    if (!w) return fail(ctx, PSEG_ERR_ARG, "pseg_wait: nothing was submitted");
+    std::unique_lock<std::mutex> lk(w->mu);
+    if (!w->have_job && !w->done) return fail(ctx, PSEG_ERR_ARG, "pseg_wait: nothing was submitted");
+    w->cv.wait(lk, [&] { return w->done; });
+    w->done = false;
+    if (out && w->rc == PSEG_OK) *out = w->table;
+    return w->rc;
+}
+static void async_stop(pseg_ctx *ctx)
+{
+    AsyncWorker *w = ctx->worker;
+    if (!w) return;
+    {
+        std::unique_lock<std::mutex> lk(w->mu);
+        w->cv.wait(lk, [&] { return !w->have_job; });       // a submitted call finishes first
+        w->quit = true;
+        w->cv.notify_all();
+    }
+    w->th.join();
+    delete w;
+    ctx->worker = nullptr;
 }
 
 extern "C" int pseg_fetch_crops(pseg_ctx *ctx, uint8_t *raw, uint8_t *masked, uint8_t *mask)

@@ -90,8 +90,9 @@ class Segmenter:
 
     def close(self):
         if getattr(self, "h", None):
-            self.L.pseg_destroy(self.h)
+            self.L.pseg_destroy(self.h)                    # (waits for a submitted call first)
             self.h = None
+            self._pending = None
 
     def __del__(self):
         try:
@@ -162,10 +163,23 @@ class Segmenter:
             saved_row=_np(t.saved_row, ns, np.int32), crop_offset=_np(t.crop_offset, ns + 1, np.int64),
             sums=_np(t.sums, ns * _lib.NSUMS, np.int64).reshape(ns, _lib.NSUMS), crop_bytes=int(t.crop_bytes))
         if fetch_crops:
-            planes = {k: np.empty(max(tab.crop_bytes, 1), np.uint8) for k in ("raw", "masked", "mask")}
+            planes = self._crop_buffers(max(tab.crop_bytes, 1), fetch_crops)
             self._chk(self.L.pseg_fetch_crops(self.h, planes["raw"].ctypes.data, planes["masked"].ctypes.data, planes["mask"].ctypes.data))
             tab.crops = {k: v[:tab.crop_bytes] for k, v in planes.items()}
         return tab
+
+    def _crop_buffers(self, nbytes, mode):
+        """host buffers of the three crop planes.  mode "pinned": page-locked memory owned by the context and reused by its
+        next fetch (the copies are single DMA transfers at PCIe rate; pageable memory goes through a staging buffer at a
+        fraction of it) -- for consumers that are done with the crops before the context's next call.  Otherwise fresh
+        NumPy arrays that the caller may keep."""
+        if mode != "pinned":
+            return {k: np.empty(nbytes, np.uint8) for k in ("raw", "masked", "mask")}
+        import torch
+        if getattr(self, "_pin_crops", None) is None or self._pin_crops.shape[1] < nbytes:
+            self._pin_crops = torch.empty((3, nbytes + nbytes // 4 + 4096), dtype=torch.uint8, pin_memory=True)
+        a = self._pin_crops.numpy()
+        return {"raw": a[0], "masked": a[1], "mask": a[2]}
 
     def detect(self, cleaned, raw=None, mask=None, valid=None, threshold=10, min_area_to_segment=10.0,
                min_area_to_save=400.0, labels=None, fetch_crops=False):
@@ -185,12 +199,8 @@ class Segmenter:
                                      None if labels is None else labels.data_ptr(), C.byref(t)))
         return self._table(t, fetch_crops)
 
-    def process(self, frames, n_bg_imgs=6, mask=None, threshold=10, min_area_to_segment=10.0, min_area_to_save=400.0,
-                cleaned=None, labels=None, fetch_crops=False, want_table=True, n_emit=None, batch_len=None):
-        """Fused hot path over one batch.  ``n_emit`` < len(frames): ``frames`` is the leading part of a batch plus its
-        forward halo (sharding.plan_ranges); only the first n_emit frames are processed and returned.
-        ``batch_len``: ``frames`` holds several consecutive reference batches of that many frames (the last may be
-        shorter), each background-corrected inside its own batch; one table over all frames."""
+    def _process_args(self, frames, n_bg_imgs, mask, threshold, min_area_to_segment, min_area_to_save, cleaned, labels, n_emit,
+                      batch_len):
         import torch
         n_avail = frames.shape[0]
         n = n_avail if n_emit is None else int(n_emit)
@@ -200,21 +210,58 @@ class Segmenter:
         self._check_frames(cleaned, n)
         if labels is not None:
             self._check_frames(labels, n, torch.int32)
-        ms = np.zeros((n, 2), np.float64)
-        valid = np.zeros(n, np.uint8)
-        t = _lib.Table()
-        torch.cuda.current_stream(frames.device).synchronize()
         if batch_len is not None and batch_len < n_avail:
             if n != n_avail:
                 raise PsegError("n_emit and batch_len exclude each other")
-            self._chk(self.L.pseg_process_batches(self.h, frames.data_ptr(), n_avail, int(batch_len), n_bg_imgs,
-                                                  None if mask is None else mask.data_ptr(), int(threshold), float(min_area_to_segment),
-                                                  float(min_area_to_save), cleaned.data_ptr(), ms.ctypes.data, valid.ctypes.data,
-                                                  None if labels is None else labels.data_ptr(), C.byref(t)))
+            bl = int(batch_len)
         else:
-            self._chk(self.L.pseg_process_part(self.h, frames.data_ptr(), n_avail, n, n_bg_imgs, None if mask is None else mask.data_ptr(),
-                                               int(threshold), float(min_area_to_segment), float(min_area_to_save), cleaned.data_ptr(),
-                                               ms.ctypes.data, valid.ctypes.data, None if labels is None else labels.data_ptr(), C.byref(t)))
+            bl = 0
+        ms = np.zeros((n, 2), np.float64)
+        valid = np.zeros(n, np.uint8)
+        torch.cuda.current_stream(frames.device).synchronize()
+        args = (frames.data_ptr(), n_avail, n, bl, n_bg_imgs, None if mask is None else mask.data_ptr(), int(threshold),
+                float(min_area_to_segment), float(min_area_to_save), cleaned.data_ptr(), ms.ctypes.data, valid.ctypes.data,
+                None if labels is None else labels.data_ptr())
+        return args, cleaned, ms, valid
+
+    def process(self, frames, n_bg_imgs=6, mask=None, threshold=10, min_area_to_segment=10.0, min_area_to_save=400.0,
+                cleaned=None, labels=None, fetch_crops=False, want_table=True, n_emit=None, batch_len=None):
+        """Fused hot path over one batch.  ``n_emit`` < len(frames): ``frames`` is the leading part of a batch plus its
+        forward halo (sharding.plan_ranges); only the first n_emit frames are processed and returned.
+        ``batch_len``: ``frames`` holds several consecutive reference batches of that many frames (the last may be
+        shorter), each background-corrected inside its own batch; one table over all frames."""
+        args, cleaned, ms, valid = self._process_args(frames, n_bg_imgs, mask, threshold, min_area_to_segment, min_area_to_save,
+                                                      cleaned, labels, n_emit, batch_len)
+        t = _lib.Table()
+        fr, n_avail, n, bl = args[:4]
+        if bl:
+            self._chk(self.L.pseg_process_batches(self.h, fr, n_avail, bl, *args[4:], C.byref(t)))
+        else:
+            self._chk(self.L.pseg_process_part(self.h, fr, n_avail, n, *args[4:], C.byref(t)))
+        tab = self._table(t, fetch_crops) if want_table else None
+        return cleaned, ms, valid, tab
+
+    def submit(self, frames, n_bg_imgs=6, mask=None, threshold=10, min_area_to_segment=10.0, min_area_to_save=400.0,
+               cleaned=None, labels=None, n_emit=None, batch_len=None):
+        """``process`` without waiting (pseg_submit): the call runs on the context's worker thread inside the library and
+        this returns at once; ``wait`` delivers what ``process`` returns.  One submission in flight per context; a caller
+        thread pipelines batches by alternating two or three contexts."""
+        if getattr(self, "_pending", None) is not None:
+            raise PsegError("submit: the previous submission has not been waited for")
+        args, cleaned, ms, valid = self._process_args(frames, n_bg_imgs, mask, threshold, min_area_to_segment, min_area_to_save,
+                                                      cleaned, labels, n_emit, batch_len)
+        self._chk(self.L.pseg_submit(self.h, *args))
+        self._pending = (cleaned, ms, valid, (frames, mask, labels))          # keeps every buffer alive until wait()
+        return self
+
+    def wait(self, fetch_crops=False, want_table=True):
+        """(cleaned, mean_std, valid, table) of the submitted call (pseg_wait)."""
+        if getattr(self, "_pending", None) is None:
+            raise PsegError("wait: nothing was submitted")
+        cleaned, ms, valid, _keep = self._pending
+        self._pending = None
+        t = _lib.Table()
+        self._chk(self.L.pseg_wait(self.h, C.byref(t)))
         tab = self._table(t, fetch_crops) if want_table else None
         return cleaned, ms, valid, tab
 
@@ -263,3 +310,64 @@ class Segmenter:
         assert off.shape[0] == n + 1 and off[-1] == objs.shape[0]
         self._chk(self.L.pseg_synth_frames(self.h, n, frame0, int(seed), objs.ctypes.data, off.ctypes.data, out.data_ptr()))
         return out
+
+
+class HostPipeline:
+    """Batches that start in host memory (decoded files, a camera buffer): upload, fused hot path and the way back of the
+    table and crops, overlapped across batches from ONE caller thread.  ``depth`` contexts (pseg_submit / pseg_wait) with a
+    page-locked staging buffer and device buffers each: while batch b computes, batch b+1 crosses PCIe (22.8 ms per
+    200 frames of 2560 x 2560 at 57 GB/s against 2 ms of kernels -- the link is the bound of this form of the path,
+    DESIGN.md section 6).  No counterpart in the reference, which moves every frame through pickled queue items
+    (segmenter.py:221-254)."""
+
+    def __init__(self, H=2560, W=2560, max_frames=200, device=0, depth=2, labels=False):
+        import torch
+        dev = f"cuda:{device}"
+        self.H, self.W, self.max_frames, self.depth = H, W, max_frames, depth
+        self.segs = [Segmenter(H, W, max_frames=max_frames, device=device) for _ in range(depth)]
+        self.host = [torch.empty((max_frames, H, W), dtype=torch.uint8, pin_memory=True) for _ in range(depth)]
+        self.raw = [torch.empty((max_frames, H, W), dtype=torch.uint8, device=dev) for _ in range(depth)]
+        self.cleaned = [torch.empty((max_frames, H, W), dtype=torch.uint8, device=dev) for _ in range(depth)]
+        self.labels = [torch.empty((max_frames, H, W), dtype=torch.int32, device=dev) if labels else None for _ in range(depth)]
+        self.copy_stream = torch.cuda.Stream(device=dev)
+        self.uploaded = [torch.cuda.Event() for _ in range(depth)]
+
+    def staging(self, k):
+        """uint8 [max_frames, H, W] NumPy view of slot k's page-locked buffer: decode / copy the next batch straight into it"""
+        return self.host[k].numpy()
+
+    def run(self, batches, mask=None, fetch_crops="pinned", **kw):
+        """``batches`` yields ``(n, source)``: source is None (the producer has filled ``staging(b % depth)[:n]`` already),
+        a uint8 NumPy array / CPU tensor [n, H, W] to copy into the staging buffer, or a page-locked CPU tensor that is
+        uploaded as it is.  Yields ``(b, cleaned_dev[:n], mean_std, valid, table)`` in batch order; the device tensors and
+        pinned crops of slot b % depth are reused by batch b + depth."""
+        import torch
+        inflight = []
+
+        def result(b0, k0, n0):
+            c, ms, v, tab = self.segs[k0].wait(fetch_crops=fetch_crops)
+            return b0, c, ms, v, tab
+        for b, (n, src) in enumerate(batches):
+            k = b % self.depth
+            if len(inflight) == self.depth:
+                yield result(*inflight.pop(0))
+            if src is None:
+                h = self.host[k][:n]
+            elif torch.is_tensor(src) and src.is_pinned():
+                h = src[:n]
+            else:
+                h = self.host[k][:n]
+                h.numpy()[...] = src.numpy() if torch.is_tensor(src) else src
+            with torch.cuda.stream(self.copy_stream):
+                self.raw[k][:n].copy_(h, non_blocking=True)
+                self.uploaded[k].record(self.copy_stream)
+            self.uploaded[k].synchronize()                  # earlier batches compute on their contexts' threads meanwhile
+            self.segs[k].submit(self.raw[k][:n], mask=mask, cleaned=self.cleaned[k][:n],
+                                labels=None if self.labels[k] is None else self.labels[k][:n], **kw)
+            inflight.append((b, k, n))
+        for it in inflight:
+            yield result(*it)
+
+    def close(self):
+        for s in self.segs:
+            s.close()

@@ -122,6 +122,19 @@ int pseg_process_batches(pseg_ctx *ctx, const uint8_t *frames, int n, int batch_
                          int threshold, double min_area_to_segment, double min_area_to_save, uint8_t *cleaned,
                          double *mean_std, uint8_t *valid, int32_t *labels, pseg_table *out);
 
+/* Asynchronous form of the fused path, for ONE caller thread that keeps several batches in flight (the reference overlaps
+ * its stages with process pools and bounded queues, segmenter.py:221-254; here the overlap is between batches).  The
+ * context owns a worker thread inside the library: pseg_submit hands it the arguments of pseg_process_part (batch_len == 0)
+ * or pseg_process_batches (batch_len > 0, n_emit == n_avail) and returns at once; pseg_wait blocks until that call has
+ * finished, returns its status and fills *out.  All pointers must stay valid until pseg_wait returns; one submission in flight
+ * per context (a second pseg_submit before pseg_wait is PSEG_ERR_ARG).  With two or three contexts on one GPU --
+ * submit(A), submit(B), wait(A), submit(A), wait(B), ... -- the host round trips and the table epilogue of one batch hide
+ * under the kernels of the next, without any thread on the caller's side.  Results are identical to the synchronous calls. */
+int pseg_submit(pseg_ctx *ctx, const uint8_t *frames, int n_avail, int n_emit, int batch_len, int n_bg_imgs,
+                const uint8_t *mask, int threshold, double min_area_to_segment, double min_area_to_save,
+                uint8_t *cleaned, double *mean_std, uint8_t *valid, int32_t *labels);
+int pseg_wait(pseg_ctx *ctx, pseg_table *out);
+
 /* Copy the three packed crop planes of the last detection to host buffers of crop_bytes each
  * (any may be NULL).  Replaces the arrays handed to cv.imwrite (detection.py:251-253). */
 int pseg_fetch_crops(pseg_ctx *ctx, uint8_t *raw, uint8_t *masked, uint8_t *mask);

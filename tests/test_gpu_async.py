@@ -1,0 +1,97 @@
+"""pseg_submit / pseg_wait: one caller thread keeps several contexts in flight; results are those of the synchronous calls."""
+import numpy as np
+import pytest
+
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+TABLE_FIELDS = ("frame_row_offset", "frame_n_contours", "frame_valid", "frame_mean", "frame_std", "frame", "c", "label", "area",
+                "x", "y", "w", "h", "saved", "saved_props", "saved_row", "crop_offset", "sums")
+
+
+def _same_table(a, b):
+    for name in TABLE_FIELDS:
+        assert np.array_equal(getattr(a, name), getattr(b, name), equal_nan=True), name
+    for plane in a.crops:
+        assert np.array_equal(a.crops[plane], b.crops[plane]), plane
+
+
+def test_pipelined_submissions_equal_synchronous_calls():
+    import torch
+    from imageprocessing_amd import synth
+    from imageprocessing_amd.engine import Segmenter
+    H, W, n, nbatch = 256, 320, 40, 7
+    segs = [Segmenter(H, W, max_frames=n, device=0) for _ in range(3)]
+    ref = Segmenter(H, W, max_frames=n, device=0)
+    try:
+        mask = torch.from_numpy(helpers.make_disk(H, W, 120)).cuda()
+        stacks = []
+        for b in range(nbatch):
+            objs, off = synth.make_objects(n, H, W, 30 + b, per_frame=12, dmin=30, dmax=500)
+            st = synth.render(n, H, W, 30 + b, objs, off)
+            if b == 2:
+                st[5] = 60                                 # a corrupt frame
+            stacks.append(torch.from_numpy(st).cuda())
+        want = []
+        for b in range(nbatch):
+            lab = torch.empty((n, H, W), dtype=torch.int32, device="cuda")
+            c, ms, v, tab = ref.process(stacks[b], mask=mask, labels=lab, fetch_crops=True)
+            want.append((c.clone(), ms.copy(), v.copy(), tab, lab))
+        # batch 0 against the oracle, so that "equal to the synchronous call" means "equal to the reference"
+        dets = helpers.oracle_detect(helpers.oracle_bgcorrect(stacks[0].cpu().numpy()), mask.cpu().numpy())
+        helpers.compare_table(want[0][3], dets, H, W, labels=want[0][4].cpu().numpy())
+        labs = [torch.empty((n, H, W), dtype=torch.int32, device="cuda") for _ in segs]
+        got = [None] * nbatch
+        inflight = []                                      # (batch, context index), oldest first
+        for b in range(nbatch):
+            k = b % len(segs)
+            if len(inflight) == len(segs):                 # the context is busy: take its result first
+                b0, k0 = inflight.pop(0)
+                assert k0 == k
+                c, ms, v, tab = segs[k0].wait(fetch_crops=True)
+                got[b0] = (c.clone(), ms.copy(), v.copy(), tab, labs[k0].clone())
+            segs[k].submit(stacks[b], mask=mask, labels=labs[k])
+            inflight.append((b, k))
+        for b0, k0 in inflight:
+            c, ms, v, tab = segs[k0].wait(fetch_crops=True)
+            got[b0] = (c.clone(), ms.copy(), v.copy(), tab, labs[k0].clone())
+        for b in range(nbatch):
+            ok = torch.from_numpy(want[b][2].astype(bool)).cuda()
+            assert torch.equal(got[b][0][ok], want[b][0][ok])
+            assert np.array_equal(got[b][1], want[b][1]) and np.array_equal(got[b][2], want[b][2])
+            _same_table(got[b][3], want[b][3])
+            assert torch.equal(got[b][4], want[b][4])
+    finally:
+        for s in segs + [ref]:
+            s.close()
+
+
+def test_submit_wait_protocol_and_errors():
+    import torch
+    from imageprocessing_amd.engine import PsegError, Segmenter
+    H, W, n = 64, 128, 14
+    seg = Segmenter(H, W, max_frames=n, device=0)
+    try:
+        rng = np.random.default_rng(1)
+        frames = torch.from_numpy(rng.integers(0, 256, (n, H, W), dtype=np.uint8)).cuda()
+        with pytest.raises(PsegError):
+            seg.wait()
+        t = seg.L.pseg_wait(seg.h, None)
+        assert t == -1                                     # nothing submitted, straight through the C ABI
+        seg.submit(frames, threshold=100)
+        with pytest.raises(PsegError):
+            seg.submit(frames, threshold=100)              # one submission in flight per context
+        c1, ms1, v1, tab1 = seg.wait()
+        c2, ms2, v2, tab2 = seg.process(frames, threshold=100)
+        assert torch.equal(c1, c2) and np.array_equal(ms1, ms2) and np.array_equal(tab1.area, tab2.area)
+        # an invalid call reports its error at wait and leaves the context usable
+        seg.submit(frames[:4])                             # fewer than n_bg_imgs frames: the reference raises IndexError
+        with pytest.raises(PsegError):
+            seg.wait()
+        seg.submit(frames, threshold=100, n_emit=2)        # a part with its forward halo
+        c3, _, _, tab3 = seg.wait()
+        assert torch.equal(c3, c2[:2]) and tab3.n_frames == 2
+        seg.submit(frames, threshold=100)                  # closing with a call in flight waits for it
+    finally:
+        seg.close()

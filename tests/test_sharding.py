@@ -117,6 +117,64 @@ def test_gather_tables_gloo_world2():
     assert r0[0] == 2 and r0[1] == rows0 + r1
 
 
+def _worker_plan(rank, world, port, q, n_files):
+    """what bench.py --gpus N does with real tables: the rank's parts of the 10 000-frame plan, one fake table per part,
+    packed with the part's global frame base, a few parts per gather message, merged on rank 0"""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    parts = sharding.plan_ranges(n_files, world)[rank]
+    gat = sharding.TableGatherer()
+    # every rank makes the same number of gather calls (a collective): the plan gives ranks equally many parts +- 1
+    nparts = [len(p) for p in sharding.plan_ranges(n_files, world)]
+    ncalls = max((k + 3) // 4 for k in nparts)
+    got, rows = [], 0
+    wire = np.empty(8 << 20, np.uint8)
+    for g in range(ncalls):
+        fill = 0
+        for p in parts[4 * g:4 * g + 4]:
+            tab = fake_table(p["n_emit"], np.random.default_rng(p["start"]))
+            rows += len(tab.frame)
+            fill += sharding.pack_table(tab, frame_base=p["start"], out=wire[fill:]).size
+        res = gat.gather(wire[:fill])
+        if rank == 0:
+            for blob in res:
+                got += [sharding.unpack_table(b) for b in sharding.split_tables(blob)]
+    if rank == 0:
+        merged = sharding.merge_tables(got)
+        frames_with_rows = np.unique(merged["frame"])
+        q.put(("merged", len(merged["frame_row_offset"]) - 1, int(merged["frame_row_offset"][-1]),
+               bool((np.diff(merged["frame"]) >= 0).all()), int(frames_with_rows.max()), rows))
+    else:
+        q.put(("rows", rows))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_frame_range_plan_gather_merge_gloo_world2():
+    import torch.multiprocessing as mp
+    n_files = 10000
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_plan, args=(r, 2, port, q, n_files)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(2)]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    m = [r for r in res if r[0] == "merged"][0]
+    other = [r for r in res if r[0] == "rows"][0]
+    assert m[1] == n_files                                  # every frame of the stack exactly once
+    assert m[2] == m[5] + other[1]                          # every row of both ranks
+    assert m[3] and m[4] <= n_files - 1                     # global (frame, c) order
+
+
 @pytest.mark.parametrize("n_files,world", [(2000, 8), (10000, 8), (450, 3), (200, 2), (30, 4), (1999, 7), (13, 2), (5, 3)])
 def test_plan_ranges_covers_every_frame_once_with_local_windows(n_files, world):
     """Every frame is emitted by exactly one part, and the background window the reference gives it
