@@ -127,7 +127,6 @@ def main():
     loaded = sum(c[2] for c in calls)
 
     gatherer = sharding.TableGatherer(device=cdev) if world > 1 else None
-    wire = np.empty(256 << 20, np.uint8) if world > 1 else None     # reused by pack_table
     group_ms = {k: 0.0 for k in GROUP_NAMES}
     stats = dict(rows=0, saved=0, crop_bytes=0, contours=0, gather_s=0.0, calls=0, frames=0)
 
@@ -147,23 +146,66 @@ def main():
             for g in GROUP_NAMES:
                 group_ms[g] += segs[k].last_ms(g)
 
+    # Table gathers: every rank makes the same number of gather calls per pass (a collective), whatever its number of parts;
+    # the tables of about GATHER_EVERY consecutive calls travel in one message, and the collective itself runs on a thread
+    # of its own so that the caller thread keeps submitting (it only packs the table: plain copies).
+    import queue as _queue
+    import threading as _threading
+    if strong:
+        n_gather = max(max((len(p) + GATHER_EVERY - 1) // GATHER_EVERY for p in sharding.plan_ranges(total_frames, world)), 1)
+    else:
+        n_gather = max((len(calls) + GATHER_EVERY - 1) // GATHER_EVERY, 1)
+    nc_ = len(calls)
+    group_end = [((g + 1) * nc_) // n_gather for g in range(n_gather)]      # calls [group_end[g-1], group_end[g]) form message g
+    wires = [np.empty(64 << 20, np.uint8) for _ in range(3)] if world > 1 else []
+    gq = _queue.Queue()
+    free_wires = _queue.Queue()
+    for w_ in wires:
+        free_wires.put(w_)
+
+    def gather_main():
+        while True:
+            it = gq.get()
+            if it is None:
+                return
+            buf, fill, timed = it
+            g0_ = time.perf_counter()
+            gatherer.gather(buf[:max(fill, 8)])
+            if timed:
+                stats["gather_s"] += time.perf_counter() - g0_
+            free_wires.put(buf)
+    gth = None
+    if world > 1:
+        gth = _threading.Thread(target=gather_main, daemon=True)
+        gth.start()
+
     class Gather:
-        """tables of GATHER_EVERY consecutive calls travel in one message: fewer, larger collectives"""
         def __init__(self):
-            self.fill, self.since = 0, 0
+            self.fill, self.g, self.buf = 0, 0, None
 
         def add(self, c, tab, last, timed):
             if world == 1:
                 return
-            t0 = time.perf_counter()
-            blob = sharding.pack_table(tab, frame_base=calls[c][3], out=wire[self.fill:])
-            self.fill += blob.size
-            self.since += 1
-            if self.since >= GATHER_EVERY or last:
-                gatherer.gather(wire[:self.fill])
-                self.fill, self.since = 0, 0
-            if timed:
-                stats["gather_s"] += time.perf_counter() - t0
+            if self.buf is None:
+                self.buf = free_wires.get()
+            self.fill += sharding.pack_table(tab, frame_base=calls[c][3], out=self.buf[self.fill:]).size
+            while self.g < n_gather and c + 1 >= group_end[self.g]:          # (also sends the empty messages of a rank with few parts)
+                gq.put((self.buf, self.fill, timed))
+                self.g += 1
+                self.fill, self.buf = 0, None
+                if self.g < n_gather and c + 1 >= group_end[self.g]:
+                    self.buf = free_wires.get()
+
+        def finish(self, timed):
+            while world > 1 and self.g < n_gather:                           # a rank without parts still takes part in every gather
+                gq.put((self.buf if self.buf is not None else free_wires.get(), self.fill, timed))
+                self.g += 1
+                self.fill, self.buf = 0, None
+
+    def gathers_done():
+        if world > 1:
+            while free_wires.qsize() < len(wires):                           # every message sent and its buffer returned
+                time.sleep(0.0002)
 
     def one_pass(timed):
         """every call of this rank once (= one step), pipelined over the contexts"""
@@ -213,15 +255,18 @@ def main():
                 gat.add(want, tab, want == nc - 1, timed)
             for t in ths:
                 t.join()
+        gat.finish(timed)
 
     for _ in range(args.warmup):
         one_pass(False)
+    gathers_done()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_pass(True)
+    gathers_done()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -311,6 +356,7 @@ def main():
                  "contexts": ns, "driver": args.driver, "results_checked_after_timed_region": checked,
                  "ranks_seen": dist.get_world_size() if world > 1 else 1,
                  "halo_overhead": round(halo, 4) if strong else 0.0,
+                 "table_gather_messages_per_step": n_gather if world > 1 else None,
                  "table_gather_ms_per_step_rank0": round(stats["gather_s"] / max(args.steps, 1) * 1e3, 3) if world > 1 else None},
     }
 
@@ -372,6 +418,8 @@ def main():
                                "sample": f"configs[0]: {nf} frames, seed 1, one batch (window 12), NumPy + C oracle, {how}, "
                                          f"no PNG/CSV writes, host has {os.cpu_count()} logical CPUs", **extra}
     if world > 1:
+        gq.put(None)
+        gth.join()
         dist.barrier()
     sys.stdout.flush()
     os.dup2(real_stdout, 1)

@@ -72,7 +72,7 @@ struct pseg_ctx {
     DevBuf rows, saved_row, saved_geo, crop_off, bits_off, maskbits, crops_raw, crops_masked, crops_mask;
     bool mask_counted = false;    // maskcnt already holds the number of mask == 255 pixels (fused background kernel)
     bool have_bits = false;       // threshold plane + masked sums already produced by the bg kernel
-    DevBuf bounds, band_off, band_obj, trash, rp_small, rp_scratch, resize_tab;
+    DevBuf bounds, band_off, band_obj, trash, rp_small, rp_scratch, resize_tab, synth_objs, synth_off;
     int bounds_n = -1, bounds_emit = -1, bounds_chunks = -1, bounds_batch = -1;
     bool runs_old = false;        // wave-per-row run extraction (k_runs) instead of k_runs_quad (PSEG_RUNS_OLD)
     bool exclusive = true;        // the device part of a call holds the GPU's turn (PSEG_EXCLUSIVE=0: batches interleave freely)
@@ -552,7 +552,8 @@ __global__ __launch_bounds__(1024) void k_reduce_partials(const uint32_t *__rest
         unsigned long long s[4] = {0, 0, 0, 0};
         for (int w = 0; w < 16; w++) for (int k = 0; k < 4; k++) s[k] += red[w][k];
         for (int k = first; k < first + count; k++) fsums[(size_t)f * 4 + k] = s[k];
-        if (setvalid) valid[f] = (P * s[1] - s[0] * s[0]) > 4ull * P * P;
+        // (128-bit: P * sum x^2 reaches 2^64 from frames of 2^24 pixels on)
+        if (setvalid) valid[f] = ((unsigned __int128)P * s[1] - (unsigned __int128)s[0] * s[0]) > (unsigned __int128)4 * P * P;
     }
 }
 
@@ -1725,7 +1726,9 @@ extern "C" int pseg_create(int device, int H, int W, int max_frames, pseg_ctx **
     if (!out) return PSEG_ERR_ARG;
     *out = nullptr;
     pseg_ctx *ctx = new pseg_ctx();
-    if (H < 2 || W < 64 || (W % 64) || H > 65535 || W > 8192 || max_frames < 1 || max_frames > 65535) {
+    // (row counts of a batch are 32-bit: max_frames * (H + 1) must stay below 2^31)
+    if (H < 2 || W < 64 || (W % 64) || H > 65535 || W > 8192 || max_frames < 1 || max_frames > 65535 ||
+        (long long)max_frames * (H + 1) >= (1LL << 31)) {
         delete ctx;
         return PSEG_ERR_ARG;
     }
@@ -1762,7 +1765,8 @@ extern "C" int pseg_destroy(pseg_ctx *ctx)
                       &ctx->bg_parent, &ctx->bg_left, &ctx->minx, &ctx->maxx, &ctx->maxy, &ctx->area2,
                       &ctx->extrank, &ctx->keptrank, &ctx->savedrank, &ctx->objlabel, &ctx->objflag, &ctx->rows,
                       &ctx->saved_row, &ctx->saved_geo, &ctx->crop_off, &ctx->bits_off, &ctx->maskbits,
-                      &ctx->crops_raw, &ctx->crops_masked, &ctx->crops_mask, &ctx->bounds, &ctx->band_off, &ctx->band_obj, &ctx->trash, &ctx->rp_small, &ctx->rp_scratch, &ctx->resize_tab};
+                      &ctx->crops_raw, &ctx->crops_masked, &ctx->crops_mask, &ctx->bounds, &ctx->band_off, &ctx->band_obj, &ctx->trash, &ctx->rp_small, &ctx->rp_scratch, &ctx->resize_tab,
+                      &ctx->synth_objs, &ctx->synth_off};
     for (DevBuf *b : bufs) if (b->p) hipFree(b->p);
     for (PinBuf *b : {&ctx->pin_head, &ctx->pin_tail, &ctx->pin_nfg}) if (b->p) hipHostFree(b->p);
     for (auto &e : ctx->ev) if (e) hipEventDestroy(e);
@@ -2798,7 +2802,7 @@ extern "C" int pseg_synth_frames(pseg_ctx *ctx, int n, int frame0, uint64_t seed
     if (!ctx || !out || !frame_obj_off || n < 1) return PSEG_ERR_ARG;
     HIPCHK(hipSetDevice(ctx->device));
     int nobj = frame_obj_off[n];
-    DevBuf dobj, doff;
+    DevBuf &dobj = ctx->synth_objs, &doff = ctx->synth_off;   // owned by the context: nothing to free on an error return
     ENSURE(dobj, (size_t)(nobj > 0 ? nobj : 1) * 8 * 4);
     ENSURE(doff, (size_t)(n + 1) * 4);
     if (nobj > 0) HIPCHK(hipMemcpy(dobj.p, objs, (size_t)nobj * 8 * 4, hipMemcpyHostToDevice));
@@ -2807,6 +2811,5 @@ extern "C" int pseg_synth_frames(pseg_ctx *ctx, int n, int frame0, uint64_t seed
                        (unsigned long long)seed, (const int32_t *)dobj.p, (const int32_t *)doff.p);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    hipFree(dobj.p); hipFree(doff.p);
     return PSEG_OK;
 }

@@ -38,14 +38,45 @@ class DetectionSettings:
 
 
 def calculate_regionprops(mask, img, device=0):
-    """detection.py:75-159: the 32 zooprocess-style properties of one mask window (mask == nonzero) over ``img``, as the
-    dict the reference builds, computed on the GPU (``pseg_regionprops``).  mask / img: 2-D uint8 arrays."""
+    """detection.py:75-159: the 32 zooprocess-style properties of ``measure.regionprops(mask, intensity_image=img)[0]`` as
+    the dict the reference builds, computed on the GPU (``pseg_regionprops``).  mask / img: 2-D uint8 arrays.
+
+    ``regionprops(...)[0]`` is the region of the SMALLEST nonzero value of ``mask`` (detect_on_img only ever passes
+    0 / 255).  The library works on the region's bounding box (``pseg_regionprops`` takes bx = by = 0 and width / height
+    from its window, and assumes no background hole), so a general mask is cut to that box here, the box offset is put
+    back into bx / by / centroid_x / centroid_y, and a region with holes gets its filled area -- and the four columns
+    derived from it -- from ``scipy.ndimage.binary_fill_holes`` exactly as scikit-image computes it (_regionprops.py:352-359).
+    An empty mask raises IndexError, as ``regionprops(...)[0]`` does."""
     import torch
-    seg = _segmenter(2560, 2560, 1, device)
-    m = torch.from_numpy(np.ascontiguousarray(mask, dtype=np.uint8)).to(f"cuda:{device}")
-    g = torch.from_numpy(np.ascontiguousarray(img, dtype=np.uint8)).to(f"cuda:{device}")
-    vals = seg.regionprops(m, g)
-    return {k: (int(v) if k in _INT_PROPS else float(v)) for k, v in zip(PROP_KEYS, vals)}
+    mask = np.asarray(mask)
+    img = np.asarray(img)
+    if mask.ndim != 2 or img.shape != mask.shape:
+        raise ValueError("mask and img must be 2-D arrays of the same shape")
+    nz = mask[mask > 0]
+    if nz.size == 0:
+        raise IndexError("list index out of range")       # what props[0] raises in the reference
+    region = mask == nz.min()
+    rows, cols = np.nonzero(region.any(axis=1))[0], np.nonzero(region.any(axis=0))[0]
+    y0, y1, x0, x1 = int(rows[0]), int(rows[-1]) + 1, int(cols[0]), int(cols[-1]) + 1
+    win = np.ascontiguousarray(region[y0:y1, x0:x1]).astype(np.uint8) * 255
+    gray = np.ascontiguousarray(img[y0:y1, x0:x1], dtype=np.uint8)
+    h, w = win.shape
+    seg = _segmenter(64, 64, 1, device, role="props")              # (the window's size travels with the call, not the context)
+    with seg.lock:
+        vals = seg.regionprops(torch.from_numpy(win).to(f"cuda:{device}"), torch.from_numpy(gray).to(f"cuda:{device}"))
+    out = {k: (int(v) if k in _INT_PROPS else float(v)) for k, v in zip(PROP_KEYS, vals)}
+    out["bx"], out["by"] = x0, y0                                   # prop.bbox[1], prop.bbox[0]
+    out["centroid_y"] += y0                                          # prop.centroid is in image coordinates,
+    out["centroid_x"] += x0                                          # prop.local_centroid in the box's
+    from scipy import ndimage as ndi
+    filled = int(ndi.binary_fill_holes(win > 0, structure=np.ones((3, 3))).sum())
+    if filled != out["area_exc"]:                                   # holes: filled_area and the columns computed from it
+        perim = out["perim."]
+        out["area_rprops"] = filled
+        out["circ."] = (4 * np.pi * filled) / perim ** 2 if perim else float("inf")
+        out["%area"] = 1 - out["area_exc"] / filled
+        out["intden"] = filled * out["mean_intensity"]
+    return out
 
 
 def save_crop_data(path, data):
@@ -57,9 +88,10 @@ def save_crop_data(path, data):
 def disk_mask(settings, shape=(2560, 2560), device=0):
     """The mask run_detection builds once per batch (detection.py:315-326); a device tensor."""
     import torch
-    seg = _segmenter(shape[0], shape[1], 1, device)
+    seg = _segmenter(shape[0], shape[1], 1, device, role="detect")
     if settings.mask_img:
-        return seg.disk_mask(settings.mask_radius)
+        with seg.lock:
+            return seg.disk_mask(settings.mask_radius)
     return torch.zeros(shape, dtype=torch.uint8, device=f"cuda:{device}")
 
 
@@ -115,23 +147,34 @@ def detect_batch(items, settings, mask, n_writers=8, device=0):
     if not good:
         return None
     def dev_stack(k):
-        if torch.is_tensor(good[0][k]):
+        first = good[0][k]
+        if torch.is_tensor(first):
+            # rows of one contiguous batch tensor, in order (what run_bg_correction(keep_on_device=True) hands over): a view
+            base, step = first._base, first.numel()
+            if base is not None and base.is_contiguous() and all(
+                    torch.is_tensor(it[k]) and it[k]._base is base and it[k].is_contiguous()
+                    and it[k].storage_offset() == first.storage_offset() + j * step for j, it in enumerate(good)):
+                j0 = (first.storage_offset() - base.storage_offset()) // step
+                return base.view(-1, *first.shape)[j0:j0 + len(good)]
             return torch.stack([it[k] for it in good]).contiguous()
         return torch.from_numpy(np.stack([it[k] for it in good])).to(dev)
     cleaned = dev_stack(1)
     raw = cleaned if all(it[0] is it[1] for it in good) else dev_stack(0)
     H, W = cleaned.shape[-2:]
-    seg = _segmenter(H, W, len(good), device)
+    seg = _segmenter(H, W, len(good), device, role="detect")
     m = None
     if settings.mask_img and mask is not None:
         m = mask if torch.is_tensor(mask) else torch.from_numpy(np.ascontiguousarray(mask)).to(dev)
     valid = np.array([1 if it[2][1] > 2 else 0 for it in good], np.uint8)          # detection.py:179
-    tab = seg.detect(cleaned, raw=raw, mask=m, valid=valid, threshold=10,
-                     min_area_to_segment=settings.min_area_to_segment, min_area_to_save=settings.min_area_to_save,
-                     fetch_crops=settings.save_crops)
-    saved_of_row = {int(r): s for s, r in enumerate(tab.saved_row)}
-    with ThreadPoolExecutor(max_workers=max(1, n_writers)) as ex:
-        list(ex.map(lambda f: _write_frame(tab, f, good[f][3], good[f][2], settings, saved_of_row), range(len(good))))
+    with seg.lock:                                                       # the crops sit in the context's page-locked buffer until
+        tab = seg.detect(cleaned, raw=raw, mask=m, valid=valid, threshold=10,    # the files are written
+                         min_area_to_segment=settings.min_area_to_segment, min_area_to_save=settings.min_area_to_save,
+                         fetch_crops="pinned" if settings.save_crops else False)
+        saved_of_row = {int(r): s for s, r in enumerate(tab.saved_row)}
+        with ThreadPoolExecutor(max_workers=max(1, n_writers)) as ex:
+            list(ex.map(lambda f: _write_frame(tab, f, good[f][3], good[f][2], settings, saved_of_row), range(len(good))))
+        if tab.crops:
+            tab.crops = {k: v.copy() for k, v in tab.crops.items()} if tab.crop_bytes < (64 << 20) else {}
     return tab
 
 

@@ -80,8 +80,10 @@ class Segmenter:
     batch, ``process`` = both fused (segmenter.py:241,254 without deconvolution)."""
 
     def __init__(self, H=2560, W=2560, max_frames=400, device=0):
+        import threading
         self.L = _lib.load()
         self.H, self.W, self.max_frames, self.device = H, W, max_frames, device
+        self.lock = threading.RLock()          # for callers that share a context between threads (one call at a time)
         h = C.c_void_p()
         rc = self.L.pseg_create(device, H, W, max_frames, C.byref(h))
         if rc != 0:

@@ -11,7 +11,8 @@
  * aborts; the reference's convention is "print and carry on").  pseg_last_error() gives the text.
  * Pointers marked [dev] are device pointers on the context's GPU (e.g. torch.Tensor.data_ptr()),
  * [host] are host pointers.  Frames are row-major uint8 [n][H][W]; W % 64 == 0, W <= 8192, H <= 65535,
- * n <= max_frames <= 65535; a saved object may be at most 2700 rows tall (convex-hull kernel).
+ * n <= max_frames <= 65535 and max_frames * (H + 1) < 2^31 (pseg_create refuses anything else with PSEG_ERR_ARG);
+ * a saved object may be at most 2700 rows tall (convex-hull kernel).
  * A context is not re-entrant: one call at a time per context (one context per Python thread/GPU).
  */
 #ifndef PISCOSEG_H

@@ -101,3 +101,24 @@ def batches_of(files, batch_size=200):
         batches.append(files[i * batch_size:(i + 1) * batch_size])
     batches.append(files[batch_size * (len(files) // batch_size - 1):])
     return batches
+
+
+def compute_radius(imgs):
+    """segmenter.py:47-63 on the frames of :45 (``imgs``: the first 10 frames, already read and resized): the mask
+    accumulates the growing filled circles exactly as the reference draws them into one array."""
+    bg = np.max(imgs, axis=0)                                                 # :47
+    bg = cv.threshold(cv.bitwise_not(bg), 180, 255, cv.THRESH_BINARY)[1].astype(np.uint8)   # :49
+    bg = cv.bitwise_not(bg)                                                   # :50
+    bg[np.where(bg == 0)] = 10                                                # :51
+    mask = np.zeros(bg.shape, dtype=np.uint8)                                 # :53
+    count_bg_px = 0
+    radius = 1000
+    while count_bg_px < 10000:                                                # :56
+        radius += 50
+        cv.circle(mask, (1280, 1280), radius, (255), -1)                      # :58
+        masked = np.bitwise_and(bg, mask)                                     # :59
+        count_bg_px = len(np.where(masked == 10)[0])                          # :60
+        if radius > 4000:
+            raise RuntimeError("compute_radius does not terminate on these frames (SURVEY.md F14)")
+    radius -= 50                                                              # :62
+    return radius

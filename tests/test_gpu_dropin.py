@@ -125,6 +125,36 @@ def test_calculate_regionprops_signature():
                 np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-7, err_msg=f"case {case} {k}")
 
 
+def test_calculate_regionprops_on_general_masks_against_skimage():
+    """The drop-in on label images whose region does not span the window, has background holes, or shares the mask with a
+    second label value -- against scikit-image 0.18.3 itself (tests/golden/regionprops_skimage_general.npz, made by
+    tests/golden/make_golden_skimage_general.py), not against the oracle."""
+    import os
+    from imageprocessing_amd import detection
+    from imageprocessing_amd.engine import PROP_KEYS
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "regionprops_skimage_general.npz"), allow_pickle=False)
+    assert list(g["keys"]) == PROP_KEYS
+    o = 0
+    offset = holes = 0
+    for (h, w), want in zip(g["shapes"], g["expected"]):
+        mask = g["masks"][o:o + h * w].reshape(h, w)
+        img = g["imgs"][o:o + h * w].reshape(h, w)
+        o += h * w
+        got = detection.calculate_regionprops(mask, img)
+        assert list(got.keys()) == PROP_KEYS
+        offset += got["bx"] > 0 or got["by"] > 0
+        holes += got["area_rprops"] != got["area_exc"]
+        for k, e in zip(PROP_KEYS, want):
+            v = float(got[k])
+            if np.isnan(e) or np.isinf(e):
+                assert (np.isnan(v) and np.isnan(e)) or v == e, (k, v, e)
+            else:
+                np.testing.assert_allclose(v, e, rtol=1e-5, atol=1e-7, err_msg=f"{h}x{w} {k}")
+    assert offset >= 10 and holes >= 8
+    with pytest.raises(IndexError):
+        detection.calculate_regionprops(np.zeros((9, 9), np.uint8), np.zeros((9, 9), np.uint8))
+
+
 def test_regionprops_of_tall_filled_windows():
     """Solid windows over a thousand rows tall and a few pixels to a few dozen pixels wide: the largest row moments a row
     band of the crop kernel can see (its band-local sums are 32-bit)."""
