@@ -66,7 +66,7 @@ struct pseg_ctx {
     DevBuf outpack;               // sums | crop_off | rows (10 columns) | saved_row, packed for ONE copy to pin_tail
     bool head_on_host = false;    // pin_head holds this call's head (pseg_process reuses it for the raw statistics)
     // sparse workspaces
-    DevBuf rowcnt, rowoff, framebase;
+    DevBuf rowcnt, rowoff, framebase, scan_state;
     DevBuf run_x, run_fy, fg_parent, ext, gapl, runlabel, bg_parent, bg_left, minx, maxx, maxy, area2, extrank,
         keptrank, savedrank, objlabel, objflag;
     DevBuf rows, saved_row, saved_geo, crop_off, bits_off, maskbits, crops_raw, crops_masked, crops_mask;
@@ -128,6 +128,8 @@ static int ensure_pin(pseg_ctx *ctx, PinBuf &b, size_t bytes)
 }
 #define ENSURE_PIN(buf, bytes) do { int r_ = ensure_pin(ctx, (buf), (bytes)); if (r_) return r_; } while (0)
 
+static inline int scan_words(const pseg_ctx *ctx, int n) { return 2 + n * ((ctx->H + 63) / 64); }   // (64 = BAND_H)
+
 // head arena for a batch of n frames (u32 words unless noted):
 //   ftot [n] | ftot3 [3n] rowbase [n+1] savedbase [n+1] | pad | fsums [4n] u64 | maskcnt u64 | totals [4] i64 | valid [n] u8
 // everything from ftot3 on is what the host reads back (one copy of head_copy_bytes from head_copy_off)
@@ -139,6 +141,7 @@ static int head_setup(pseg_ctx *ctx, int n)
     size_t o_valid = o_totals + 32, o_end = o_valid + (size_t)n;
     ENSURE(ctx->head, o_end + 64);
     ENSURE(ctx->framebase, (size_t)(n + 2) * 4);             // [n] = total runs, [n+1] = largest band (read back together)
+    ENSURE(ctx->scan_state, (size_t)scan_words(ctx, n) * 8); // look-back scan of k_runs_band: ticket, error flag, one word per band
     ENSURE_PIN(ctx->pin_head, o_end - o_ftot3 + 64);
     ENSURE_PIN(ctx->pin_nfg, 64);
     char *b = (char *)ctx->head.p;
@@ -519,10 +522,13 @@ __global__ __launch_bounds__(1024) void k_reduce_partials(const uint32_t *__rest
                                                           unsigned long long *__restrict__ fsums, uint8_t *__restrict__ valid,
                                                           int setvalid, int first, int count,
                                                           unsigned long long *__restrict__ cnt_totals, uint32_t *__restrict__ bandmax,
-                                                          const uint32_t *__restrict__ maskpart, int nmaskpart)
+                                                          const uint32_t *__restrict__ maskpart, int nmaskpart,
+                                                          unsigned long long *__restrict__ scan, int nscan)
 {
     __shared__ unsigned long long red[16][4];
     int f = blockIdx.x;
+    // every block clears its share of the look-back scan's state (ticket, error flag, one word per band: k_runs_band)
+    for (int i = f * 1024 + threadIdx.x; i < nscan; i += gridDim.x * 1024) scan[i] = 0;
     // block 0 also clears the counters of the detection that follows (mask count | 4 totals, largest band) and, when the
     // background kernel left per-wave counts of mask pixels, sums them
     if (f == 0 && cnt_totals) {
@@ -694,78 +700,6 @@ __global__ __launch_bounds__(256) void k_runs(SegState S, int nrows)
         if (!FILL && lane == 0) S.rowcnt[row] = total;
     }
 }
-// The same extraction with four lanes per row (wave = 16 rows): a lane walks its quarter of the row's words in order,
-// so the carry between words stays in the lane and a row costs a handful of instructions per word instead of a wave-wide
-// scan per row.  Starts are rare (about one word in fifty holds one), the walk over the words is the whole cost.
-template <bool FILL, int WPL>
-__global__ __launch_bounds__(256) void k_runs_quad(SegState S, int nrows, int wpl, uint32_t cap)
-{
-    // FILL is launched before the host knows the run count, into the buffers of the previous batch: nothing is written
-    // when the runs do not fit (cap = entries of run_x / run_fy; the host then grows the buffers and launches again)
-    if (FILL && S.framebase[S.F] > cap) return;
-    const int lane = threadIdx.x & 63, part = lane & 3;
-    const int row = (blockIdx.x * 4 + (int)(threadIdx.x >> 6)) * RUNS_RPW + (lane >> 2);
-    bool want = row < nrows;
-    int f = 0, y = 0;
-    if (want) {
-        f = row / S.H; y = row - f * S.H;
-        if (!S.valid[f]) want = false;
-        else if (FILL && seg_rowcount(S, f, y) == 0) want = false;
-    }
-    const uint64_t *rb = S.bits + (size_t)(want ? row : 0) * S.WW;
-    const int w0 = part * wpl, nw = want ? (w0 + wpl < S.WW ? wpl : S.WW - w0) : 0;     // nw <= wpl <= WPL (may be <= 0)
-    // all words of the lane are requested at once: one memory latency per wave
-    uint64_t v[WPL];
-#pragma unroll
-    for (int k = 0; k < WPL; k++) v[k] = k < nw ? rb[w0 + k] : 0;
-    const uint64_t before = (w0 > 0 && nw > 0) ? rb[w0 - 1] : 0;
-    uint32_t cnt = 0;
-    {
-        uint64_t prev = before;
-#pragma unroll
-        for (int k = 0; k < WPL; k++) {
-            cnt += (uint32_t)__popcll(v[k] & ~((v[k] << 1) | (prev >> 63)));
-            prev = v[k];
-        }
-    }
-    // counts of the row's four lanes (quad broadcasts)
-    const uint32_t c0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cnt, 0x00, 0xf, 0xf, false);
-    const uint32_t c1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cnt, 0x55, 0xf, 0xf, false);
-    const uint32_t c2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cnt, 0xAA, 0xf, 0xf, false);
-    if (!FILL) {
-        const uint32_t c3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cnt, 0xFF, 0xf, 0xf, false);
-        if (part == 0 && row < nrows) S.rowcnt[row] = c0 + c1 + c2 + c3;
-        return;
-    }
-    if (cnt == 0) return;
-    int idx = seg_rowstart(S, f, y) + (int)((part > 0 ? c0 : 0u) + (part > 1 ? c1 : 0u) + (part > 2 ? c2 : 0u));
-    const uint32_t fy = (uint32_t)y | ((uint32_t)f << 16);
-    uint64_t prev = before;
-#pragma unroll
-    for (int k = 0; k < WPL; k++) {
-        const uint64_t vv = v[k];
-        uint64_t st = vv & ~((vv << 1) | (prev >> 63));
-        prev = vv;
-        const int w = w0 + k;
-        while (st) {
-            const int s = __ffsll((unsigned long long)st) - 1;
-            st &= st - 1;
-            const uint64_t t = ~(vv >> s);                   // zeros mark the run's extent from bit s
-            const int ones = t ? __ffsll((unsigned long long)t) - 1 : 64;
-            int xe = 64 * w + s + ones - 1;
-            if (s + ones == 64)                              // the run goes on into the next words (possibly another lane's)
-                for (int q = w + 1; q < S.WW; q++) {
-                    const uint64_t u = rb[q];
-                    if (u == ~0ull) { xe += 64; continue; }
-                    xe += __ffsll((unsigned long long)~u) - 1;
-                    break;
-                }
-            S.run_x[idx] = (uint32_t)(64 * w + s) | ((uint32_t)xe << 16);
-            S.run_fy[idx] = fy;
-            idx++;
-        }
-    }
-}
 __global__ void k_init(SegState S, int nfg, int nt) { size_t g = GTID; if (g < (size_t)nt) init_body(S, (int)g, nfg); }
 // both union passes in one launch (two independent union-find structures)
 __global__ void k_unions(SegState S, int nfg, int nt, int bandh)
@@ -775,11 +709,16 @@ __global__ void k_unions(SegState S, int nfg, int nt, int bandh)
     if (g < (size_t)nt) bg_union_body(S, (int)g, nfg, bandh);
 }
 
+#define BAND_H 64
+#define BAND_CAP 1024
 // unions across the band boundaries only: block = the first row of a band (y = BAND_H, 2 BAND_H, ...) of one frame, a
 // thread per run (its foreground unions with the row above, and the gap on its left) plus one for the trailing gap.  The
 // per-element launch (k_unions over all runs and gaps) has one thread in BAND_H with work.
-__global__ __launch_bounds__(64) void k_unions_rows(SegState S, int bandh)
+__global__ __launch_bounds__(64) void k_unions_rows(SegState S, int bandh, uint32_t cap, const uint32_t *__restrict__ bandmax)
 {
+    // (queued behind k_runs_band before the host has seen the totals: nothing to do when the runs did not fit the tables
+    // or a band was too large for the LDS labelling -- the host then takes another path)
+    if (cap == 0 || S.framebase[S.F] > cap || *bandmax > BAND_CAP) return;
     const int f = blockIdx.y, y = ((int)blockIdx.x + 1) * bandh;
     if (y >= S.H) return;
     const int rs = seg_rowstart(S, f, y), n = seg_rowcount(S, f, y);
@@ -796,8 +735,6 @@ __global__ __launch_bounds__(64) void k_unions_rows(SegState S, int bandh)
 // frame-connected background (smallest background index of the frame, seg_b0) is the virtual node -1 here.  Also does
 // the work of k_init for the band.  Used when no band of the batch has more than BAND_CAP runs (k_scan_rows reports
 // the maximum); otherwise the host takes the global path.
-#define BAND_H 64
-#define BAND_CAP 1024
 __device__ __forceinline__ int lds_find(int *par, int a)
 {
     if (a < 0) return -1;
@@ -829,7 +766,7 @@ __global__ __launch_bounds__(256) void k_band_label(SegState S)
     const int f = blockIdx.y, y0 = blockIdx.x * BAND_H, H = S.H;
     const int nr = (y0 + BAND_H <= H) ? BAND_H : H - y0;  // rows in this band
     const uint32_t *ro = S.rowoff + (size_t)f * (H + 1) + y0;
-    const int R0 = (int)(S.framebase[f] + ro[0]);         // global index of the band's first run
+    const int R0 = (int)ro[0];                            // global index of the band's first run
     const int nb = (int)(ro[nr] - ro[0]);                 // runs in the band (<= BAND_CAP, checked by the host)
     const int B0g = seg_b0(S, f), Bb = R0 + f * H + y0;   // global background indices: frame-connected / band base
     for (int t = threadIdx.x; t <= nr; t += 256) lrow[t] = (int)(ro[t] - ro[0]);
@@ -884,6 +821,218 @@ __global__ __launch_bounds__(256) void k_band_label(SegState S)
         S.bg_parent[Bb + i] = rt < 0 ? B0g : Bb + rt;
     }
 }
+// ---- run extraction + scan + band labelling in ONE pass over the threshold plane ---------------------------------------
+// Block = one band of BAND_H rows of one frame, wave = 16 rows, four lanes per row: a lane requests its quarter of the
+// row's 64-bit words at once (one memory latency per wave) and walks them in order, so the carry between words stays in
+// the lane; run starts  v & ~(v << 1 | carry)  are rare (one word in fifty).  A DPP scan over the wave (lane order = raster
+// order) and the four wave totals give every lane the band-local index of its first run.
+// The global index needs the number of runs in all bands before this one (frame-major, band-major = raster order): a
+// decoupled look-back scan (Merrill / Garland) over the blocks.  Blocks take a ticket when they start, so every block with
+// a smaller ticket is running or done; a block publishes its total (AGGREGATE) as soon as it has counted, wave 0 sums its
+// predecessors' totals 64 at a time until it meets one that already knows its INCLUSIVE prefix, and publishes its own.
+// The runs are staged in LDS, labelled there (same union-find as k_band_label: 8-connected foreground, 4-connected
+// background, the frame-connected background as the virtual node -1) and leave the block once, with global indices, in
+// coalesced stores -- the plane is read once, and the run tables are not read back.
+// Launched before the host knows the run count, into the buffers as they stand: nothing is written to the run tables
+// beyond `cap` entries (the totals still come out right; the host then grows the buffers and launches again).  A band with
+// more than BAND_CAP runs skips the LDS labelling and writes its runs directly; bandmax tells the host to label globally.
+// scan[0] = ticket counter, scan[2 + t] = state of block t: flag << 62 | value.  All cleared by k_reduce_partials.
+#define SCAN_AGG (1ull << 62)
+#define SCAN_INC (2ull << 62)
+#define SCAN_SPIN_MAX (1 << 22)
+template <int WPL>
+__global__ __launch_bounds__(256) void k_runs_band(SegState S, int wpl, uint32_t cap, unsigned long long *__restrict__ scan,
+                                                   uint32_t *__restrict__ bandmax)
+{
+    __shared__ uint32_t lx[BAND_CAP];                     // run_x of the band's runs
+    __shared__ uint16_t ly[BAND_CAP];                     // band-local row of every run
+    __shared__ int fgp[BAND_CAP], bgp[BAND_CAP + BAND_H];
+    __shared__ int lrow[BAND_H + 1];                      // local index of the first run of every row
+    __shared__ uint32_t wtot[4];
+    __shared__ uint32_t s_ticket, s_base;
+    const int H = S.H, nbpf = (H + BAND_H - 1) / BAND_H;
+    if (threadIdx.x == 0) s_ticket = (uint32_t)atomicAdd(&scan[0], 1ull);
+    __syncthreads();
+    const int t = (int)s_ticket;
+    const int f = t / nbpf, band = t - f * nbpf, y0 = band * BAND_H;
+    const int nr = (y0 + BAND_H <= H) ? BAND_H : H - y0;  // rows in this band
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, part = lane & 3;
+    const int yl = wv * 16 + (lane >> 2), y = y0 + yl;
+    const bool inband = yl < nr;
+    const bool want = inband && S.valid[f];
+    const uint64_t *rb = S.bits + ((size_t)f * H + (inband ? y : y0)) * S.WW;
+    const int w0 = part * wpl, nw = want ? (w0 + wpl < S.WW ? wpl : S.WW - w0) : 0;     // nw <= wpl <= WPL (may be <= 0)
+    uint64_t v[WPL];
+#pragma unroll
+    for (int k = 0; k < WPL; k++) v[k] = k < nw ? rb[w0 + k] : 0;
+    const uint64_t before = (w0 > 0 && nw > 0) ? rb[w0 - 1] : 0;
+    uint32_t cnt = 0;
+    {
+        uint64_t prev = before;
+#pragma unroll
+        for (int k = 0; k < WPL; k++) {
+            cnt += (uint32_t)__popcll(v[k] & ~((v[k] << 1) | (prev >> 63)));
+            prev = v[k];
+        }
+    }
+    const uint32_t incl = wave_scan_incl(cnt);            // lane order = (row, quarter) = raster order
+    if (lane == 63) wtot[wv] = incl;
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (int w = 0; w < wv; w++) wbase += wtot[w];
+    const uint32_t nb = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&scan[2 + t], (t == 0 ? SCAN_INC : SCAN_AGG) | nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == 0) s_base = 0;
+        if (nb > *(volatile uint32_t *)bandmax) atomicMax(bandmax, nb);      // (a stale read only costs a redundant atomic)
+        lrow[BAND_H] = (int)nb;
+    }
+    const uint32_t li = wbase + incl - cnt;               // band-local index of the lane's first run
+    if (part == 0) lrow[yl] = (int)li;
+    const bool fits = nb <= BAND_CAP;
+    // the lane's runs: into LDS when the band fits, else straight to memory once the base is known
+    auto emit_runs = [&](auto &&put) {
+        uint64_t prev = before;
+        uint32_t idx = li;
+#pragma unroll
+        for (int k = 0; k < WPL; k++) {
+            const uint64_t vv = v[k];
+            uint64_t st = vv & ~((vv << 1) | (prev >> 63));
+            prev = vv;
+            const int w = w0 + k;
+            while (st) {
+                const int s0 = __ffsll((unsigned long long)st) - 1;
+                st &= st - 1;
+                const uint64_t z = ~(vv >> s0);             // zeros mark the run's extent from bit s0
+                const int ones = z ? __ffsll((unsigned long long)z) - 1 : 64;
+                int xe = 64 * w + s0 + ones - 1;
+                if (s0 + ones == 64)                        // the run goes on into the next words (possibly another lane's)
+                    for (int q = w + 1; q < S.WW; q++) {
+                        const uint64_t u = rb[q];
+                        if (u == ~0ull) { xe += 64; continue; }
+                        xe += __ffsll((unsigned long long)~u) - 1;
+                        break;
+                    }
+                put(idx++, (uint32_t)(64 * w + s0) | ((uint32_t)xe << 16));
+            }
+        }
+    };
+    if (fits && cnt) emit_runs([&](uint32_t i, uint32_t rx) { lx[i] = rx; ly[i] = (uint16_t)yl; });
+    __syncthreads();
+    // global background index of the band's first gap.  That gap (the leading gap of the band's first row) touches the
+    // padding column x = -1, so it stands for the frame-connected background (the virtual node -1) of this band; the
+    // representatives of a frame's bands are united by k_unions_rows across the band boundaries, and the smallest one is
+    // seg_b0(S, f) -- the frame's first background index, which only the block of band 0 could know here
+    if (fits) {
+        // init (k_init's work for this band)
+        for (int i = threadIdx.x; i < (int)nb; i += 256) {
+            const int yy = ly[i], j = i - lrow[yy], ya = y0 + yy;
+            fgp[i] = i;
+            bgp[i + yy] = (j == 0 || ya == 0 || ya == H - 1) ? -1 : i + yy;
+        }
+        for (int yy = threadIdx.x; yy < nr; yy += 256) bgp[lrow[yy + 1] + yy] = -1;      // trailing gap of every row
+        __syncthreads();
+        // unions with the previous row of the band (rows yy >= 1)
+        for (int i = threadIdx.x; i < (int)nb + nr; i += 256) {
+            int yy, j, n;
+            if (i < (int)nb) { yy = ly[i]; j = i - lrow[yy]; n = lrow[yy + 1] - lrow[yy]; }
+            else { yy = i - (int)nb; n = lrow[yy + 1] - lrow[yy]; j = n; }                 // trailing gap of row yy
+            if (yy == 0) continue;
+            const int ps = lrow[yy - 1], pn = lrow[yy] - ps, rs = lrow[yy];
+            if (i < (int)nb && pn > 0) {                         // foreground, 8-connectivity (fg_union_body)
+                const int lo = (int)(lx[i] & 0xffffu) - 1, hi = (int)(lx[i] >> 16) + 1;
+                int a = ps, b = ps + pn;                         // first q with xe_q >= lo
+                while (a < b) { const int m = (a + b) >> 1; if ((int)(lx[m] >> 16) >= lo) b = m; else a = m + 1; }
+                for (int q = a; q < ps + pn && (int)(lx[q] & 0xffffu) <= hi; q++) lds_union(fgp, i, q);
+            }
+            {                                                    // background, 4-connectivity (bg_union_elem)
+                const int ga = j == 0 ? -1 : (int)(lx[rs + j - 1] >> 16) + 1;
+                const int ge = j == n ? S.W : (int)(lx[rs + j] & 0xffffu) - 1;
+                const int g = rs + j + yy, pb = ps + (yy - 1);
+                int lo = 0, hi = pn;                             // first gap of the previous row whose right end >= ga
+                while (lo < hi) { const int m = (lo + hi) >> 1; if ((int)(lx[ps + m] & 0xffffu) >= ga + 1) hi = m; else lo = m + 1; }
+                for (int q = lo; q <= pn; q++) {
+                    const int qa = q == 0 ? -1 : (int)(lx[ps + q - 1] >> 16) + 1;
+                    if (qa > ge) break;
+                    lds_union(bgp, g, pb + q);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // decoupled look-back, after the labelling (most predecessors know their inclusive prefix by now): the whole block
+    // reads 256 predecessor states per round, every wave sums its 64 up to the nearest inclusive one
+    __shared__ uint32_t lb_sum[4], lb_hit[4];
+    if (t > 0) {
+        uint32_t excl = 0;
+        int pos = t - 1;
+        bool timeout = false;
+        for (;;) {
+            const int idx = pos - (int)threadIdx.x;
+            unsigned long long sv = SCAN_INC;               // before block 0: inclusive prefix 0
+            if (idx >= 0) {
+                int spins = 0;
+                for (;;) {
+                    sv = __hip_atomic_load(&scan[2 + idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((sv >> 62) != 0 || ++spins >= SCAN_SPIN_MAX) break;
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                if ((sv >> 62) == 0) { timeout = true; sv = SCAN_INC; }      // never expected; the host reports it
+            }
+            const unsigned long long incm = __ballot((sv >> 62) == 2);
+            const int L = incm ? (int)__builtin_ctzll(incm) : 64;
+            const uint32_t part_sum = wave_sum63(lane <= L ? (uint32_t)sv : 0u);
+            if (lane == 63) { lb_sum[wv] = part_sum; lb_hit[wv] = incm != 0; }
+            if (timeout) scan[1] = 1;
+            __syncthreads();
+            bool hit = false;
+            for (int w = 0; w < 4 && !hit; w++) { excl += lb_sum[w]; hit = lb_hit[w] != 0; }
+            __syncthreads();
+            if (hit) break;
+            pos -= 256;
+        }
+        if (threadIdx.x == 0) {
+            s_base = excl;
+            __hip_atomic_store(&scan[2 + t], SCAN_INC | (unsigned long long)(excl + nb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+    }
+    const int R0 = (int)s_base;                           // global index of the band's first run
+    // (cap == 0: the tables do not exist yet -- not even the background entries every row owns without any run)
+    const bool room = cap > 0 && (unsigned long long)R0 + nb <= (unsigned long long)cap;
+    // row table (global indices), frame bases, the grand total
+    if (part == 0 && inband) S.rowoff[(size_t)f * (H + 1) + y] = (uint32_t)R0 + li;
+    if (threadIdx.x == 0) {
+        if (band == nbpf - 1) S.rowoff[(size_t)f * (H + 1) + H] = (uint32_t)R0 + nb;
+        if (band == 0) S.framebase[f] = (uint32_t)R0;
+        if (t == nbpf * S.F - 1) S.framebase[S.F] = (uint32_t)R0 + nb;
+    }
+    if (!room) return;
+    if (!fits) {                                          // too many runs for the LDS tables: the host labels globally (k_init, k_unions)
+        const uint32_t fy = (uint32_t)y | ((uint32_t)f << 16);
+        if (cnt) emit_runs([&](uint32_t i, uint32_t rx) { S.run_x[R0 + i] = rx; S.run_fy[R0 + i] = fy; });
+        return;
+    }
+    const int Bb = R0 + f * H + y0;                       // global background index of the band's first gap (see below)
+    // flatten and publish: runs, parents (global indices), the per-object accumulators' start values
+    for (int i = threadIdx.x; i < (int)nb + nr; i += 256) {
+        if (i < (int)nb) {
+            const int r = R0 + i, yy = ly[i], j = i - lrow[yy];
+            S.run_x[r] = lx[i];
+            S.run_fy[r] = (uint32_t)(y0 + yy) | ((uint32_t)f << 16);
+            S.fg_parent[r] = R0 + lds_find(fgp, i);
+            S.bg_left[Bb + i + yy] = j == 0 ? -1 : r - 1;
+            S.minx[r] = 0x7fffffff; S.maxx[r] = -1; S.maxy[r] = -1; S.area2[r] = 0;
+        }
+        const int rt = lds_find(bgp, i);
+        S.bg_parent[Bb + i] = rt < 0 ? Bb : Bb + rt;
+    }
+    for (int yy = threadIdx.x; yy < nr; yy += 256) {        // trailing gap of every row
+        const int g = lrow[yy + 1] + yy;
+        S.bg_left[Bb + g] = lrow[yy + 1] == lrow[yy] ? -1 : R0 + lrow[yy + 1] - 1;
+    }
+}
+
 // flatten + enclosure tree in one launch: every parent is followed to its root on the fly (the parents other threads
 // flatten meanwhile are only ever replaced by one of their ancestors, so a chain stays a chain to the same root)
 __global__ void k_flatten_resolve(SegState S, int nfg, int nbg)
@@ -994,6 +1143,14 @@ __global__ __launch_bounds__(256) void k_scan_rows(SegState S, uint32_t *ftot, u
         for (int w = 1; w < 4; w++) bm = wtot[w] > bm ? wtot[w] : bm;
         if (bm > *(volatile uint32_t *)bandmax) atomicMax(bandmax, bm);      // (a stale read only costs a redundant atomic)
     }
+}
+
+// two-pass path (k_runs): the row table becomes global run indices, like the one k_runs_band writes
+__global__ void k_rowoff_global(SegState S)
+{
+    size_t g = GTID;
+    if (g >= (size_t)S.F * (S.H + 1)) return;
+    S.rowoff[g] += S.framebase[g / (S.H + 1)];
 }
 
 // exclusive scan over the frames by one block: out[0..F] (strided input / output)
@@ -1761,7 +1918,7 @@ extern "C" int pseg_destroy(pseg_ctx *ctx)
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->bits, &ctx->partials, &ctx->maskpart, &ctx->head, &ctx->outpack, &ctx->rowspans, &ctx->rowcnt,
-                      &ctx->rowoff, &ctx->framebase, &ctx->run_x, &ctx->run_fy, &ctx->fg_parent, &ctx->ext, &ctx->gapl, &ctx->runlabel,
+                      &ctx->rowoff, &ctx->framebase, &ctx->scan_state, &ctx->run_x, &ctx->run_fy, &ctx->fg_parent, &ctx->ext, &ctx->gapl, &ctx->runlabel,
                       &ctx->bg_parent, &ctx->bg_left, &ctx->minx, &ctx->maxx, &ctx->maxy, &ctx->area2,
                       &ctx->extrank, &ctx->keptrank, &ctx->savedrank, &ctx->objlabel, &ctx->objflag, &ctx->rows,
                       &ctx->saved_row, &ctx->saved_geo, &ctx->crop_off, &ctx->bits_off, &ctx->maskbits,
@@ -1931,7 +2088,8 @@ static int run_bg(pseg_ctx *ctx, const uint8_t *frames, int n_avail, int n_emit,
     hipLaunchKernelGGL(k_reduce_partials, dim3(n), dim3(1024), 0, ctx->stream, (const uint32_t *)ctx->partials.p, (int)npart,
                        (unsigned long long)P, (unsigned long long *)ctx->fsums.p, (uint8_t *)ctx->valid_dev.p, 1, 0, 4,
                        (unsigned long long *)ctx->maskcnt.p, (uint32_t *)ctx->framebase.p + n + 1,
-                       (const uint32_t *)ctx->maskpart.p, (stream && mask) ? (int)npart : 0);
+                       (const uint32_t *)ctx->maskpart.p, (stream && mask) ? (int)npart : 0,
+                       (unsigned long long *)ctx->scan_state.p, scan_words(ctx, n));
     ctx->mask_counted = stream && mask;
     HIPCHK(hipGetLastError());
     return 0;
@@ -2069,26 +2227,52 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
     // (the counters were cleared by k_reduce_partials; the mask pixels were counted by the background kernel when it ran fused)
     if (mask && !ctx->mask_counted)
         hipLaunchKernelGGL(k_mask_count, dim3(1024), dim3(256), 0, st, mask, P, (unsigned long long *)ctx->maskcnt.p);
-    const int runs_wpl = (S.WW + 3) / 4;                     // words per lane of k_runs_quad
+    const int runs_wpl = (S.WW + 3) / 4;                     // words per lane of k_runs_band
+    const bool fused = !(ctx->runs_old || runs_wpl > 16);    // rows wider than 4096 px take the two-pass extraction (k_runs)
+    const int nbpf = (H + BAND_H - 1) / BAND_H;
+    uint32_t *bandmax_d = S.framebase + n + 1;
+    unsigned long long *scan = (unsigned long long *)ctx->scan_state.p;
+    auto set_tables = [&]() {
+        S.run_x = (uint32_t *)ctx->run_x.p; S.run_fy = (uint32_t *)ctx->run_fy.p;
+        S.fg_parent = (int32_t *)ctx->fg_parent.p; S.ext = (int32_t *)ctx->ext.p; S.gapl = (int32_t *)ctx->gapl.p;
+        S.bg_parent = (int32_t *)ctx->bg_parent.p; S.bg_left = (int32_t *)ctx->bg_left.p;
+        S.minx = (int32_t *)ctx->minx.p; S.maxx = (int32_t *)ctx->maxx.p; S.maxy = (int32_t *)ctx->maxy.p;
+        S.area2 = (int32_t *)ctx->area2.p;
+        S.extrank = (int32_t *)ctx->extrank.p; S.keptrank = (int32_t *)ctx->keptrank.p; S.savedrank = (int32_t *)ctx->savedrank.p;
+    };
+    auto launch_fused = [&](uint32_t capv) {
+        if (runs_wpl > 10) hipLaunchKernelGGL((k_runs_band<16>), dim3(nbpf * n), dim3(256), 0, st, S, runs_wpl, capv, scan, bandmax_d);
+        else hipLaunchKernelGGL((k_runs_band<10>), dim3(nbpf * n), dim3(256), 0, st, S, runs_wpl, capv, scan, bandmax_d);
+        if (H > BAND_H) hipLaunchKernelGGL(k_unions_rows, dim3((H - 1) / BAND_H, n), dim3(64), 0, st, S, BAND_H, capv, (const uint32_t *)bandmax_d);
+    };
+    uint32_t spec_cap = 0;
     const dim3 runs_grid(nblocks((size_t)n * H, 4 * RUNS_RPW));
-    if (ctx->runs_old || runs_wpl > 16) hipLaunchKernelGGL(k_runs<false>, runs_grid, dim3(256), 0, st, S, n * H);       // rows wider than 4096 px
-    else if (runs_wpl > 10) hipLaunchKernelGGL((k_runs_quad<false, 16>), runs_grid, dim3(256), 0, st, S, n * H, runs_wpl, 0u);
-    else hipLaunchKernelGGL((k_runs_quad<false, 10>), runs_grid, dim3(256), 0, st, S, n * H, runs_wpl, 0u);
-    hipLaunchKernelGGL(k_scan_rows, dim3(n), dim3(256), 0, st, S, ftot, S.framebase + n + 1);
-    hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(256), 0, st, (const uint32_t *)ftot, S.framebase, n, 1, 1);
+    if (fused) {
+        // One pass over the plane extracts, counts, scans and labels (k_runs_band), queued before the host knows the run count
+        // into the tables as they stand: capacity = what every table the kernel writes can hold
+        size_t c = ctx->run_x.bytes;
+        for (const DevBuf *b : {&ctx->run_fy, &ctx->fg_parent, &ctx->minx, &ctx->maxx, &ctx->maxy, &ctx->area2}) c = b->bytes < c ? b->bytes : c;
+        size_t cb = ctx->bg_parent.bytes < ctx->bg_left.bytes ? ctx->bg_parent.bytes : ctx->bg_left.bytes;
+        c /= 4; cb /= 4;
+        cb = cb > (size_t)n * H ? cb - (size_t)n * H : 0;
+        c = cb < c ? cb : c;
+        spec_cap = (uint32_t)(c > 0x3fffffffu ? 0x3fffffffu : c);
+        set_tables();
+        launch_fused(spec_cap);
+    } else {
+        hipLaunchKernelGGL(k_runs<false>, runs_grid, dim3(256), 0, st, S, n * H);
+        hipLaunchKernelGGL(k_scan_rows, dim3(n), dim3(256), 0, st, S, ftot, bandmax_d);
+        hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(256), 0, st, (const uint32_t *)ftot, S.framebase, n, 1, 1);
+        hipLaunchKernelGGL(k_rowoff_global, dim3(nblocks((size_t)n * (H + 1))), dim3(256), 0, st, S);
+    }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(ctx->pin_nfg.p, S.framebase + n, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync((char *)ctx->pin_nfg.p + 16, scan + 1, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipEventRecord(ctx->ev[8], st));
-    // the run tables are filled while the host waits for the count, into the buffers as they stand (see k_runs_quad)
-    const size_t spec_bytes = ctx->run_x.bytes < ctx->run_fy.bytes ? ctx->run_x.bytes : ctx->run_fy.bytes;
-    const uint32_t spec_cap = (ctx->runs_old || runs_wpl > 16) ? 0u : (uint32_t)(spec_bytes / 4 > 0x3fffffffu ? 0x3fffffffu : spec_bytes / 4);
-    if (spec_cap > 0) {
-        S.run_x = (uint32_t *)ctx->run_x.p; S.run_fy = (uint32_t *)ctx->run_fy.p;
-        if (runs_wpl > 10) hipLaunchKernelGGL((k_runs_quad<true, 16>), runs_grid, dim3(256), 0, st, S, n * H, runs_wpl, spec_cap);
-        else hipLaunchKernelGGL((k_runs_quad<true, 10>), runs_grid, dim3(256), 0, st, S, n * H, runs_wpl, spec_cap);
-    }
     HIPCHK(hipEventSynchronize(ctx->ev[8]));
     const uint32_t nfg_u = ((const volatile uint32_t *)ctx->pin_nfg.p)[0], bandmax = ((const volatile uint32_t *)ctx->pin_nfg.p)[1];
+    if (fused && ((const volatile uint64_t *)ctx->pin_nfg.p)[2] != 0)
+        return fail(ctx, PSEG_ERR_HIP, "k_runs_band: a block waited for its predecessors' totals for too long");
     if (nfg_u > 0x3fffffffu) return fail(ctx, PSEG_ERR_CAPACITY, "too many foreground runs");
     const int nfg = (int)nfg_u, nbg = nfg + n * H;
     const size_t cap = (size_t)(nfg > 0 ? nfg : 1);
@@ -2097,23 +2281,24 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
     ENSURE(ctx->minx, cap * 4); ENSURE(ctx->maxx, cap * 4); ENSURE(ctx->maxy, cap * 4);
     ENSURE(ctx->area2, cap * 4); ENSURE(ctx->extrank, cap * 4); ENSURE(ctx->keptrank, cap * 4); ENSURE(ctx->savedrank, cap * 4);
     ENSURE(ctx->objlabel, cap * 4); ENSURE(ctx->objflag, cap * 4); ENSURE(ctx->runlabel, cap * 4);
-    S.run_x = (uint32_t *)ctx->run_x.p; S.run_fy = (uint32_t *)ctx->run_fy.p;
-    S.fg_parent = (int32_t *)ctx->fg_parent.p; S.ext = (int32_t *)ctx->ext.p; S.gapl = (int32_t *)ctx->gapl.p;
-    S.bg_parent = (int32_t *)ctx->bg_parent.p; S.bg_left = (int32_t *)ctx->bg_left.p;
-    S.minx = (int32_t *)ctx->minx.p; S.maxx = (int32_t *)ctx->maxx.p; S.maxy = (int32_t *)ctx->maxy.p;
-    S.area2 = (int32_t *)ctx->area2.p;
-    S.extrank = (int32_t *)ctx->extrank.p; S.keptrank = (int32_t *)ctx->keptrank.p; S.savedrank = (int32_t *)ctx->savedrank.p;
+    set_tables();
     int32_t *objlabel = (int32_t *)ctx->objlabel.p, *objflag = (int32_t *)ctx->objflag.p;
 
-    const bool runs_done = spec_cap > 0 && nfg_u <= spec_cap;     // (the buffers were not reallocated then: cap <= their size)
-    if (nfg > 0 && (ctx->runs_old || runs_wpl > 16)) hipLaunchKernelGGL(k_runs<true>, runs_grid, dim3(256), 0, st, S, n * H);
-    else if (nfg > 0 && !runs_done && runs_wpl > 10) hipLaunchKernelGGL((k_runs_quad<true, 16>), runs_grid, dim3(256), 0, st, S, n * H, runs_wpl, 0xffffffffu);
-    else if (nfg > 0 && !runs_done) hipLaunchKernelGGL((k_runs_quad<true, 10>), runs_grid, dim3(256), 0, st, S, n * H, runs_wpl, 0xffffffffu);
-    if (bandmax <= BAND_CAP && !ctx->no_bands) {
-        // bands of BAND_H rows are labelled in LDS; the global kernels only unite across the band boundaries
-        hipLaunchKernelGGL(k_band_label, dim3((H + BAND_H - 1) / BAND_H, n), dim3(256), 0, st, S);
-        if (H > BAND_H) hipLaunchKernelGGL(k_unions_rows, dim3((H - 1) / BAND_H, n), dim3(64), 0, st, S, BAND_H);
-    } else {
+    const bool runs_done = fused && spec_cap > 0 && nfg_u <= spec_cap;       // (the tables were not reallocated then: cap <= their size)
+    const bool bands_ok = bandmax <= BAND_CAP && !ctx->no_bands;
+    if (fused && !runs_done) {                               // the tables were too small (first batch, or a denser one): once more
+        HIPCHK(hipMemsetAsync(scan, 0, (size_t)scan_words(ctx, n) * 8, st));
+        launch_fused(0xffffffffu);
+    }
+    if (!fused) {
+        if (nfg > 0) hipLaunchKernelGGL(k_runs<true>, runs_grid, dim3(256), 0, st, S, n * H);
+        if (bands_ok) {
+            // bands of BAND_H rows are labelled in LDS; the global kernels only unite across the band boundaries
+            hipLaunchKernelGGL(k_band_label, dim3(nbpf, n), dim3(256), 0, st, S);
+            if (H > BAND_H) hipLaunchKernelGGL(k_unions_rows, dim3((H - 1) / BAND_H, n), dim3(64), 0, st, S, BAND_H, 0xffffffffu, (const uint32_t *)bandmax_d);
+        }
+    }
+    if (!bands_ok) {                                         // frames too dense for the LDS tables (or PSEG_NO_BANDS): global union-find
         hipLaunchKernelGGL(k_init, dim3(nblocks(nbg)), dim3(256), 0, st, S, nfg, nbg);
         hipLaunchKernelGGL(k_unions, dim3(nblocks(nbg)), dim3(256), 0, st, S, nfg, nbg, 0);
     }
@@ -2294,7 +2479,8 @@ extern "C" int pseg_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t 
     HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
     hipLaunchKernelGGL(k_reduce_partials, dim3(n), dim3(1024), 0, ctx->stream, (const uint32_t *)ctx->partials.p, (int)nblk,
                        (unsigned long long)P, (unsigned long long *)ctx->fsums.p, (uint8_t *)ctx->valid_dev.p, 0, 2, 2,
-                       (unsigned long long *)ctx->maskcnt.p, (uint32_t *)ctx->framebase.p + n + 1, (const uint32_t *)nullptr, 0);
+                       (unsigned long long *)ctx->maskcnt.p, (uint32_t *)ctx->framebase.p + n + 1, (const uint32_t *)nullptr, 0,
+                       (unsigned long long *)ctx->scan_state.p, scan_words(ctx, n));
     ctx->mask_counted = false;
     HIPCHK(hipGetLastError());
     r = run_detect(ctx, cleaned, raw, mask, n, min_area_to_segment, min_area_to_save, labels, out);

@@ -46,7 +46,7 @@ struct SegState {
     const uint64_t *bits;            // [F][H][WW] threshold plane, bit b of word w = pixel 64w+b
     const uint8_t *valid;            // [F] 0 = corrupt frame (treated as empty)
     uint32_t *rowcnt;                // [F*H] foreground runs per row
-    uint32_t *rowoff;                // [F*(H+1)] exclusive scan of rowcnt inside the frame
+    uint32_t *rowoff;                // [F*(H+1)] global index of the first run of every row (+ one end entry per frame)
     uint32_t *framebase;             // [F+1] exclusive scan of runs per frame
     // per foreground run (global index r = framebase[f] + rowoff[f][y] + j)
     uint32_t *run_x;                 // xs | xe << 16
@@ -63,15 +63,15 @@ struct SegState {
     int32_t *extrank, *keptrank, *savedrank;   // exclusive ranks inside the frame
 };
 
-PSEG_HD int seg_rowstart(const SegState &S, int f, int y) { return (int)(S.framebase[f] + S.rowoff[f * (S.H + 1) + y]); }
+PSEG_HD int seg_rowstart(const SegState &S, int f, int y) { return (int)S.rowoff[f * (S.H + 1) + y]; }
 PSEG_HD int seg_rowcount(const SegState &S, int f, int y) { return (int)(S.rowoff[f * (S.H + 1) + y + 1] - S.rowoff[f * (S.H + 1) + y]); }
 PSEG_HD int seg_bgbase(const SegState &S, int f, int y) { return seg_rowstart(S, f, y) + f * S.H + y; }
 PSEG_HD int seg_b0(const SegState &S, int f) { return (int)S.framebase[f] + f * S.H; }   // smallest background index of frame f
 PSEG_HD int run_xs(const SegState &S, int r) { return (int)(S.run_x[r] & 0xffffu); }
 PSEG_HD int run_xe(const SegState &S, int r) { return (int)(S.run_x[r] >> 16); }
 
-// Runs are extracted in two passes over the plane (k_runs_quad / k_runs in piscoseg.hip, count then fill): starts =
-// v & ~((v << 1) | carry) per 64-bit word, a scan of the per-row counts gives every row its first run index.
+// Runs are extracted in one pass over the plane (k_runs_band in piscoseg.hip: starts = v & ~((v << 1) | carry) per 64-bit
+// word, a look-back scan over the bands gives every row its first run index), or in two for very wide rows (k_runs).
 
 // ---- union-find (link the larger root under the smaller one) -------------------------------
 PSEG_HD int uf_find(const int32_t *parent, int a)
