@@ -207,65 +207,74 @@ def main():
             while free_wires.qsize() < len(wires):                           # every message sent and its buffer returned
                 time.sleep(0.0002)
 
-    def one_pass(timed):
-        """every call of this rank once (= one step), pipelined over the contexts"""
-        gat = Gather()
+    def run_passes(count, timed):
+        """count passes over this rank's calls (count steps), as ONE pipelined sequence of library calls over the contexts:
+        the pipeline is not drained between passes"""
         nc = len(calls)
+        total = count * nc
+        state = {"gat": None}
+
+        def done(i, k, tab, ms=None):
+            c = i % nc
+            if c == 0:
+                state["gat"] = Gather()
+            if ms is None:
+                account(c, k, tab, timed)
+            elif timed:
+                stats["rows"] += tab.n_rows; stats["saved"] += len(tab.saved_row); stats["crop_bytes"] += tab.crop_bytes
+                stats["contours"] += int(tab.frame_n_contours.sum()); stats["calls"] += 1; stats["frames"] += calls[c][1]
+                for g in GROUP_NAMES:
+                    group_ms[g] += ms[g]
+            state["gat"].add(c, tab, c == nc - 1, timed)
+            if c == nc - 1:
+                state["gat"].finish(timed)
         if args.driver == "submit":
             inflight = []
-            for c in range(nc):
-                k = c % ns
+            for i in range(total):
+                k = i % ns
                 if len(inflight) == ns:
-                    c0, k0 = inflight.pop(0)
-                    tab = segs[k0].wait()[3]
-                    account(c0, k0, tab, timed)
-                    gat.add(c0, tab, False, timed)
+                    i0, k0 = inflight.pop(0)
+                    done(i0, k0, segs[k0].wait()[3])
+                c = i % nc
                 a, ne, na, _ = calls[c]
                 segs[k].submit(stack[a:a + na], **kwargs(c, k))
-                inflight.append((c, k))
-            for i, (c0, k0) in enumerate(inflight):
-                tab = segs[k0].wait()[3]
-                account(c0, k0, tab, timed)
-                gat.add(c0, tab, i == len(inflight) - 1, timed)
+                inflight.append((i, k))
+            for i0, k0 in inflight:
+                done(i0, k0, segs[k0].wait()[3])
         else:
             import queue
             import threading
             out_q = queue.Queue()
 
             def work(k):
-                for c in range(k, nc, ns):
+                for i in range(k, total, ns):
+                    c = i % nc
                     a, ne, na, _ = calls[c]
                     tab = segs[k].process(stack[a:a + na], **kwargs(c, k))[3]
-                    ms = {g: segs[k].last_ms(g) for g in GROUP_NAMES}
-                    out_q.put((c, k, tab, ms))
+                    out_q.put((i, k, tab, {g: segs[k].last_ms(g) for g in GROUP_NAMES}))
             ths = [threading.Thread(target=work, args=(k,)) for k in range(ns)]
             for t in ths:
                 t.start()
             pending = {}
-            for want in range(nc):
+            for want in range(total):
                 while want not in pending:
-                    c, k, tab, ms = out_q.get()
-                    pending[c] = (k, tab, ms)
+                    i, k, tab, ms = out_q.get()
+                    pending[i] = (k, tab, ms)
                 k, tab, ms = pending.pop(want)
-                if timed:
-                    stats["rows"] += tab.n_rows; stats["saved"] += len(tab.saved_row); stats["crop_bytes"] += tab.crop_bytes
-                    stats["contours"] += int(tab.frame_n_contours.sum()); stats["calls"] += 1; stats["frames"] += calls[want][1]
-                    for g in GROUP_NAMES:
-                        group_ms[g] += ms[g]
-                gat.add(want, tab, want == nc - 1, timed)
+                done(want, k, tab, ms)
             for t in ths:
                 t.join()
-        gat.finish(timed)
+        if nc == 0:
+            for _ in range(count):
+                Gather().finish(timed)
 
-    for _ in range(args.warmup):
-        one_pass(False)
+    run_passes(args.warmup, False)
     gathers_done()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_pass(True)
+    run_passes(args.steps, True)
     gathers_done()
     torch.cuda.synchronize()
     if world > 1:

@@ -50,7 +50,10 @@ struct RowsDev {           // device SoA of the kept-object rows
 struct pseg_ctx {
     int device = 0, H = 0, W = 0, WW = 0, maxF = 0;
     size_t P = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr; // the context's own stream
+    hipStream_t cur = nullptr;    // where work is queued right now: the device's shared streaming stream while the context holds
+                                  // the GPU's turn (GpuTurn), else `stream`
+    hipEvent_t ev_turn = nullptr; // recorded behind the streaming part on the shared stream; the own stream waits for it
     bool own_stream = false;
     std::string err;
     hipEvent_t ev[9] = {};         // 0..7 time the kernel groups, 8 marks the run count on its way to the host
@@ -76,6 +79,7 @@ struct pseg_ctx {
     int bounds_n = -1, bounds_emit = -1, bounds_chunks = -1, bounds_batch = -1;
     bool runs_old = false;        // wave-per-row run extraction (k_runs) instead of k_runs_quad (PSEG_RUNS_OLD)
     bool exclusive = true;        // the device part of a call holds the GPU's turn (PSEG_EXCLUSIVE=0: batches interleave freely)
+    bool shared_stream = false;   // PSEG_SHARED_STREAM=1: the streaming parts of all contexts go through one stream per device (GpuTurn)
     bool early_release = true;    // hand the turn on behind the label fill instead of behind the last kernel (PSEG_EARLY_RELEASE=0)
     struct GpuTurn *turn = nullptr;
     int bg_chunks = 1;            // time chunks of the streaming background kernel (PSEG_BG_CHUNKS)
@@ -89,6 +93,8 @@ struct pseg_ctx {
     int n_saved = 0;
     // host views of the last table (page-locked tail buffer): rows [10][t_hr], saved_row, crop_off
     const int32_t *t_rows = nullptr, *t_saved_row = nullptr; const int64_t *t_crop_off = nullptr; size_t t_hr = 1;
+    int spec_hold = 0;            // calls for which the fast path stays off (after a batch too dense for the LDS labelling)
+    size_t runcap = 0;            // runs the tables are sized for: the labelling chain is queued against it without a host round trip
     struct AsyncWorker *worker = nullptr;   // pseg_submit / pseg_wait: the context's own host thread (started on first use)
 };
 
@@ -131,16 +137,16 @@ static int ensure_pin(pseg_ctx *ctx, PinBuf &b, size_t bytes)
 static inline int scan_words(const pseg_ctx *ctx, int n) { return 2 + n * ((ctx->H + 63) / 64); }   // (64 = BAND_H)
 
 // head arena for a batch of n frames (u32 words unless noted):
-//   ftot [n] | ftot3 [3n] rowbase [n+1] savedbase [n+1] | pad | fsums [4n] u64 | maskcnt u64 | totals [4] i64 | valid [n] u8
+//   ftot [n] | ftot3 [3n] rowbase [n+1] savedbase [n+1] | pad | fsums [4n] u64 | maskcnt u64 | totals [8] i64 | valid [n] u8
 // everything from ftot3 on is what the host reads back (one copy of head_copy_bytes from head_copy_off)
 static int head_setup(pseg_ctx *ctx, int n)
 {
     if (ctx->head_n == n) return 0;
     size_t o_ftot = 0, o_ftot3 = (size_t)n * 4, o_end32 = o_ftot3 + ((size_t)5 * n + 2) * 4;
     size_t o_fsums = (o_end32 + 7) & ~(size_t)7, o_maskcnt = o_fsums + (size_t)n * 32, o_totals = o_maskcnt + 8;
-    size_t o_valid = o_totals + 32, o_end = o_valid + (size_t)n;
+    size_t o_valid = o_totals + 64, o_end = o_valid + (size_t)n;
     ENSURE(ctx->head, o_end + 64);
-    ENSURE(ctx->framebase, (size_t)(n + 2) * 4);             // [n] = total runs, [n+1] = largest band (read back together)
+    ENSURE(ctx->framebase, (size_t)(n + 3) * 4);             // [n] = total runs, [n+1] = largest band, [n+2] = scan error flag
     ENSURE(ctx->scan_state, (size_t)scan_words(ctx, n) * 8); // look-back scan of k_runs_band: ticket, error flag, one word per band
     ENSURE_PIN(ctx->pin_head, o_end - o_ftot3 + 64);
     ENSURE_PIN(ctx->pin_nfg, 64);
@@ -169,7 +175,7 @@ static HeadHost head_host(const pseg_ctx *ctx, int n)
     h.fsums = (const uint64_t *)(b + o_fsums);
     h.maskcnt = *(const uint64_t *)(b + o_fsums + (size_t)n * 32);
     h.totals = (const long long *)(b + o_fsums + (size_t)n * 32 + 8);
-    h.valid = (const uint8_t *)(b + o_fsums + (size_t)n * 32 + 40);
+    h.valid = (const uint8_t *)(b + o_fsums + (size_t)n * 32 + 72);
     return h;
 }
 
@@ -533,7 +539,7 @@ __global__ __launch_bounds__(1024) void k_reduce_partials(const uint32_t *__rest
     // background kernel left per-wave counts of mask pixels, sums them
     if (f == 0 && cnt_totals) {
         if (threadIdx.x >= 1 && threadIdx.x < 5) cnt_totals[threadIdx.x] = 0;
-        if (threadIdx.x == 5) *bandmax = 0;
+        if (threadIdx.x == 5) { bandmax[0] = 0; bandmax[1] = 0; }
         unsigned long long m = 0;
         for (int b = threadIdx.x; b < nmaskpart; b += 1024) m += maskpart[b];
         for (int o = 32; o > 0; o >>= 1) m += __shfl_down(m, o, 64);
@@ -711,6 +717,14 @@ __global__ void k_unions(SegState S, int nfg, int nt, int bandh)
 
 #define BAND_H 64
 #define BAND_CAP 1024
+// The kernels of the labelling chain are queued before the host has seen the run count (no host round trip in the middle
+// of a call): they are sized by the capacity of the run tables and do nothing when the runs did not fit (cap) or when a band
+// had too many runs for the LDS labelling (bcap); the host then repeats the chain the slow way.  framebase[F] = runs of the
+// batch, [F + 1] = largest band, [F + 2] = error flag of the look-back scan.
+__device__ __forceinline__ bool chain_ok(const SegState &S, uint32_t cap, uint32_t bcap)
+{
+    return S.framebase[S.F] <= cap && S.framebase[S.F + 1] <= bcap;
+}
 // unions across the band boundaries only: block = the first row of a band (y = BAND_H, 2 BAND_H, ...) of one frame, a
 // thread per run (its foreground unions with the row above, and the gap on its left) plus one for the trailing gap.  The
 // per-element launch (k_unions over all runs and gaps) has one thread in BAND_H with work.
@@ -718,7 +732,7 @@ __global__ __launch_bounds__(64) void k_unions_rows(SegState S, int bandh, uint3
 {
     // (queued behind k_runs_band before the host has seen the totals: nothing to do when the runs did not fit the tables
     // or a band was too large for the LDS labelling -- the host then takes another path)
-    if (cap == 0 || S.framebase[S.F] > cap || *bandmax > BAND_CAP) return;
+    if (cap == 0 || !chain_ok(S, cap, BAND_CAP)) return;
     const int f = blockIdx.y, y = ((int)blockIdx.x + 1) * bandh;
     if (y >= S.H) return;
     const int rs = seg_rowstart(S, f, y), n = seg_rowcount(S, f, y);
@@ -983,7 +997,7 @@ __global__ __launch_bounds__(256) void k_runs_band(SegState S, int wpl, uint32_t
             const int L = incm ? (int)__builtin_ctzll(incm) : 64;
             const uint32_t part_sum = wave_sum63(lane <= L ? (uint32_t)sv : 0u);
             if (lane == 63) { lb_sum[wv] = part_sum; lb_hit[wv] = incm != 0; }
-            if (timeout) scan[1] = 1;
+            if (timeout) bandmax[1] = 1;
             __syncthreads();
             bool hit = false;
             for (int w = 0; w < 4 && !hit; w++) { excl += lb_sum[w]; hit = lb_hit[w] != 0; }
@@ -1035,8 +1049,10 @@ __global__ __launch_bounds__(256) void k_runs_band(SegState S, int wpl, uint32_t
 
 // flatten + enclosure tree in one launch: every parent is followed to its root on the fly (the parents other threads
 // flatten meanwhile are only ever replaced by one of their ancestors, so a chain stays a chain to the same root)
-__global__ void k_flatten_resolve(SegState S, int nfg, int nbg)
+__global__ void k_flatten_resolve(SegState S, uint32_t cap, uint32_t bcap)
 {
+    if (!chain_ok(S, cap, bcap)) return;
+    const int nfg = (int)S.framebase[S.F], nbg = nfg + S.F * S.H;
     size_t g = GTID;
     if (g < (size_t)nbg) S.bg_parent[g] = uf_find(S.bg_parent, (int)g);
     if (g >= (size_t)nfg) return;
@@ -1054,9 +1070,11 @@ __global__ void k_flatten_resolve(SegState S, int nfg, int nbg)
 }
 // bounding boxes: the 256 runs of a block are combined per object in an LDS hash table first, so that
 // only one set of global atomics is issued per (block, object)
-__global__ __launch_bounds__(256) void k_bbox(SegState S, int nfg)
+__global__ __launch_bounds__(256) void k_bbox(SegState S, uint32_t cap, uint32_t bcap)
 {
     __shared__ int keys[512], vminx[512], vmaxx[512], vmaxy[512];
+    if (!chain_ok(S, cap, bcap)) return;
+    const int nfg = (int)S.framebase[S.F];
     for (int i = threadIdx.x; i < 512; i += 256) { keys[i] = -1; vminx[i] = 0x7fffffff; vmaxx[i] = -1; vmaxy[i] = -1; }
     __syncthreads();
     size_t g = GTID;
@@ -1081,9 +1099,11 @@ __global__ __launch_bounds__(256) void k_bbox(SegState S, int nfg)
 }
 // contour areas: the contributions of a block's 256 runs are summed per object in an LDS hash table first (a large
 // object receives one contribution per row and span: hundreds of atomics on one word otherwise)
-__global__ __launch_bounds__(256) void k_area(SegState S, int nfg)
+__global__ __launch_bounds__(256) void k_area(SegState S, uint32_t cap, uint32_t bcap)
 {
     __shared__ int keys[512], vsum[512];
+    if (!chain_ok(S, cap, bcap)) return;
+    const int nfg = (int)S.framebase[S.F];
     for (int i = threadIdx.x; i < 512; i += 256) { keys[i] = -1; vsum[i] = 0; }
     __syncthreads();
     size_t g = GTID;
@@ -1183,10 +1203,11 @@ __global__ __launch_bounds__(256) void k_scan_small(const uint32_t *in, uint32_t
 
 // ranks of external roots / kept / saved objects inside each frame (block per frame).
 // ftot3[f*3+{0,1,2}] = number of external contours, kept, saved.
-__global__ __launch_bounds__(1024) void k_rank(SegState S, double min_seg, double min_save, uint32_t *ftot3)
+__global__ __launch_bounds__(1024) void k_rank(SegState S, double min_seg, double min_save, uint32_t *ftot3, uint32_t cap, uint32_t bcap)
 {
     __shared__ uint32_t wtot[16][3];
     __shared__ uint32_t carry[3];
+    if (!chain_ok(S, cap, bcap)) return;
     const int f = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int r0 = (int)S.framebase[f], r1 = (int)S.framebase[f + 1];
     if (threadIdx.x < 3) carry[threadIdx.x] = 0;
@@ -1219,10 +1240,12 @@ __global__ __launch_bounds__(1024) void k_rank(SegState S, double min_seg, doubl
 }
 
 // one row per kept object, ordered (frame, c); c counts from the LAST external root (detection.py:222)
-__global__ void k_emit(SegState S, int nfg, double min_seg, double min_save, const uint32_t *ftot3, const uint32_t *rowbase,
-                       const uint32_t *savedbase, RowsDev R, int32_t *objlabel, int32_t *objflag, int32_t *saved_row,
-                       int32_t *runlabel)
+__global__ void k_emit(SegState S, uint32_t cap, uint32_t bcap, double min_seg, double min_save, const uint32_t *ftot3,
+                       const uint32_t *rowbase, const uint32_t *savedbase, RowsDev R, int32_t *objlabel, int32_t *objflag,
+                       int32_t *saved_row, int32_t *runlabel)
 {
+    if (!chain_ok(S, cap, bcap)) return;
+    const int nfg = (int)S.framebase[S.F];
     size_t g = GTID;
     if (g >= (size_t)nfg) return;
     int r = (int)g;
@@ -1259,8 +1282,10 @@ __global__ void k_emit(SegState S, int nfg, double min_seg, double min_save, con
 typedef int32_t i32x4_t __attribute__((ext_vector_type(4)));
 // grid = (ceil(W / 1024), H, frames): row and frame come from the block index (no divisions; at one KiB per wave the
 // kernel only streams at full rate while a wave spends a few dozen instructions)
-__global__ __launch_bounds__(256) void k_label_fill(SegState S, const int32_t *__restrict__ runlabel, int32_t *__restrict__ labels)
+__global__ __launch_bounds__(256) void k_label_fill(SegState S, const int32_t *__restrict__ runlabel, int32_t *__restrict__ labels,
+                                                    uint32_t cap, uint32_t bcap)
 {
+    if (!chain_ok(S, cap, bcap)) return;                    // (queued with the chain: see chain_ok)
     const int lane = threadIdx.x & 63;
     const int f = blockIdx.z, y = blockIdx.y;
     const int x0 = blockIdx.x * 1024 + (threadIdx.x >> 6) * 256, x = x0 + 4 * lane;
@@ -1318,9 +1343,10 @@ __host__ __device__ inline int crop_rows_per_band(int w)
     if (r > 600) r = 600;
     return r < 1 ? 1 : r;
 }
-__global__ void k_saved_geo(const uint32_t *n_saved_p, const int32_t *saved_row, RowsDev R, int32_t *geo, unsigned long long *sz,
-                            long long *)
+__global__ void k_saved_geo(SegState S, uint32_t cap, uint32_t bcap, const uint32_t *n_saved_p, const int32_t *saved_row, RowsDev R,
+                            int32_t *geo, unsigned long long *sz)
 {
+    if (!chain_ok(S, cap, bcap)) return;
     size_t g = GTID;
     if (g >= (size_t)*n_saved_p) return;
     int i = saved_row[g];
@@ -1335,11 +1361,15 @@ __global__ void k_saved_geo(const uint32_t *n_saved_p, const int32_t *saved_row,
 // exclusive scans of the three size columns by one block of 1024 threads; out[k][0..n].  A thread takes 8 consecutive
 // objects (one pass of wave / block scans per 8192 objects)
 #define SCAN_IPT 8
-__global__ __launch_bounds__(1024) void k_scan_sizes(const unsigned long long *sz, const uint32_t *n_p, long long *crop_off,
-                                                      long long *bits_off, long long *band_off, long long *totals)
+__global__ __launch_bounds__(1024) void k_scan_sizes(SegState S, uint32_t cap, uint32_t bcap, const unsigned long long *sz,
+                                                      const uint32_t *n_p, long long *crop_off, long long *bits_off,
+                                                      long long *band_off, long long *totals)
 {
     __shared__ unsigned long long wtot[16][3];
     __shared__ unsigned long long carry[3];
+    // totals[4..6]: runs of the batch, largest band, scan error flag -- what the host needs to accept or repeat the chain
+    if (threadIdx.x < 3) totals[4 + threadIdx.x] = (long long)S.framebase[S.F + threadIdx.x];
+    if (!chain_ok(S, cap, bcap)) { if (threadIdx.x < 4) totals[threadIdx.x] = 0; return; }
     const int n = (int)*n_p, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (threadIdx.x < 3) carry[threadIdx.x] = 0;
     __syncthreads();
@@ -1892,8 +1922,12 @@ extern "C" int pseg_create(int device, int H, int W, int max_frames, pseg_ctx **
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device || device < 0) { delete ctx; return PSEG_ERR_NODEVICE; }
     ctx->device = device; ctx->H = H; ctx->W = W; ctx->WW = W / 64; ctx->maxF = max_frames; ctx->P = (size_t)H * W;
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&ctx->stream) != hipSuccess) { delete ctx; return PSEG_ERR_HIP; }
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return PSEG_ERR_HIP; }
+    // (non-blocking streams: a caller that synchronises the legacy default stream -- torch's current stream, before it hands
+    // over its tensors -- must not wait for the batches other contexts have in flight on the library's streams)
     ctx->own_stream = true;
+    ctx->cur = ctx->stream;
+    if (hipEventCreateWithFlags(&ctx->ev_turn, hipEventDisableTiming) != hipSuccess) ctx->ev_turn = nullptr;
     if (rp_static_lookup(device) != hipSuccess) { hipStreamDestroy(ctx->stream); delete ctx; return PSEG_ERR_HIP; }
     if (const char *e = getenv("PSEG_BG_CHUNKS")) ctx->bg_chunks = atoi(e) > 0 ? atoi(e) : 1;
     if (const char *e = getenv("PSEG_BG_GENERIC")) ctx->force_generic = atoi(e) != 0;
@@ -1904,6 +1938,7 @@ extern "C" int pseg_create(int device, int H, int W, int max_frames, pseg_ctx **
     }
     if (const char *e = getenv("PSEG_EXCLUSIVE")) ctx->exclusive = atoi(e) != 0;
     if (const char *e = getenv("PSEG_EARLY_RELEASE")) ctx->early_release = atoi(e) != 0;
+    if (const char *e = getenv("PSEG_SHARED_STREAM")) ctx->shared_stream = atoi(e) != 0;
     if (const char *e = getenv("PSEG_RUNS_OLD")) ctx->runs_old = atoi(e) != 0;
     if (const char *e = getenv("PSEG_NO_BANDS")) ctx->no_bands = atoi(e) != 0;
     for (auto &e : ctx->ev) if (hipEventCreate(&e) != hipSuccess) { pseg_destroy(ctx); return PSEG_ERR_HIP; }   // frees what exists so far
@@ -1927,6 +1962,7 @@ extern "C" int pseg_destroy(pseg_ctx *ctx)
     for (DevBuf *b : bufs) if (b->p) hipFree(b->p);
     for (PinBuf *b : {&ctx->pin_head, &ctx->pin_tail, &ctx->pin_nfg}) if (b->p) hipHostFree(b->p);
     for (auto &e : ctx->ev) if (e) hipEventDestroy(e);
+    if (ctx->ev_turn) hipEventDestroy(ctx->ev_turn);
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
     return PSEG_OK;
@@ -1940,6 +1976,7 @@ extern "C" int pseg_set_stream(pseg_ctx *ctx, void *hip_stream)
     if (!ctx) return PSEG_ERR_ARG;
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
     ctx->stream = (hipStream_t)hip_stream;
+    ctx->cur = ctx->stream;
     ctx->own_stream = false;
     return PSEG_OK;
 }
@@ -1964,31 +2001,78 @@ static int check_batch(pseg_ctx *ctx, int n)
 // Other pairings were traced and dropped: the crop chain beside the next batch's labelling kernels (both stretch: 0.64 ms
 // against 0.40 + 0.38 ms, and the background kernel alone again) comes out level.
 #define PSEG_MAX_DEVICES 64
-static std::mutex g_turn_mu[PSEG_MAX_DEVICES];
-static hipEvent_t g_turn_ev[PSEG_MAX_DEVICES];              // recorded behind the last kernel of the previous holder
+// first come, first served: with a plain mutex a context that has just finished can overtake one that has been waiting, and a
+// caller that collects its results in submission order (pseg_submit / pseg_wait) then sits on the overtaken one while the
+// others have nothing queued -- the pipeline runs dry (80 us of idle GPU per batch in the kernel trace)
+struct TurnLock {
+    std::mutex m;
+    std::condition_variable cv;
+    unsigned long long next = 0, serving = 0;
+    void lock()
+    {
+        std::unique_lock<std::mutex> lk(m);
+        const unsigned long long my = next++;
+        cv.wait(lk, [&] { return serving == my; });
+    }
+    void unlock()
+    {
+        { std::lock_guard<std::mutex> lk(m); serving++; }
+        cv.notify_all();
+    }
+};
+static TurnLock g_turn_mu[PSEG_MAX_DEVICES];
+static hipEvent_t g_turn_ev[PSEG_MAX_DEVICES];              // recorded behind the last streaming kernel of the previous holder
 static bool g_turn_ev_set[PSEG_MAX_DEVICES];
-// The hand-over happens on the device: the holder records the event behind its last kernel and lets go while that kernel
-// is still queued; the next holder makes its stream wait for the event and can queue its first kernels at once.
+static hipStream_t g_turn_last[PSEG_MAX_DEVICES];            // the stream that event was recorded on
+static hipStream_t g_main_stream[PSEG_MAX_DEVICES];          // the device's shared streaming stream
+static bool g_main_tried[PSEG_MAX_DEVICES];
+static hipStream_t g_tail_stream[PSEG_MAX_DEVICES][2];       // where the tails of consecutive calls go, alternating
+static unsigned g_tail_next[PSEG_MAX_DEVICES];
+// The streaming parts of consecutive batches (background kernel ... label fill) are queued on ONE stream per device, in
+// turn order: the next batch's background kernel follows the label fill in the same hardware queue with no cross-queue
+// dependency in between (a wait on another queue's event cost about 70 us of idle device per batch in the kernel trace).
+// The latency-bound tail of a call (crops, properties, hulls, copies) goes to one of two tail streams of the device (taken
+// in turns), behind an event recorded at the hand-over, and runs beside the next batch's background kernel.  Three streams
+// per device whatever the number of contexts: a process has few hardware queues (GPU_MAX_HW_QUEUES, 4 by default), and
+// streams that share one run in order -- with a stream per context the tail of one batch and the background kernel of the
+// next landed in the same queue and ran one after the other.  A context on a caller's stream
+// (pseg_set_stream) keeps everything on that stream and is ordered against the others through g_turn_ev.
 struct GpuTurn {
     pseg_ctx *ctx; bool held = false;
     explicit GpuTurn(pseg_ctx *c) : ctx(c)
     {
         if (!c || !c->exclusive || c->turn || c->device < 0 || c->device >= PSEG_MAX_DEVICES) return;
-        g_turn_mu[c->device].lock();
+        const int d = c->device;
+        g_turn_mu[d].lock();
         held = true; c->turn = this;
-        if (g_turn_ev_set[c->device]) (void)hipStreamWaitEvent(c->stream, g_turn_ev[c->device], 0);
+        if (c->own_stream && c->ev_turn && c->shared_stream) {
+            if (!g_main_tried[d]) {
+                g_main_tried[d] = true;
+                if (hipStreamCreateWithFlags(&g_main_stream[d], hipStreamNonBlocking) != hipSuccess) g_main_stream[d] = nullptr;
+                for (auto &t : g_tail_stream[d]) if (hipStreamCreateWithFlags(&t, hipStreamNonBlocking) != hipSuccess) t = nullptr;
+            }
+            if (g_main_stream[d]) c->cur = g_main_stream[d];
+        }
+        if (g_turn_ev_set[d] && g_turn_last[d] != c->cur) (void)hipStreamWaitEvent(c->cur, g_turn_ev[d], 0);
     }
-    void release()                                           // call after the last kernel of the device part is queued
+    void release()                                           // call after the last kernel of the streaming part is queued
     {
         if (!held) return;
         const int d = ctx->device;
         if (!g_turn_ev_set[d]) g_turn_ev_set[d] = hipEventCreateWithFlags(&g_turn_ev[d], hipEventDisableTiming) == hipSuccess;
-        if (g_turn_ev_set[d]) (void)hipEventRecord(g_turn_ev[d], ctx->stream);
-        else (void)hipStreamSynchronize(ctx->stream);        // no event: hand over on the host
+        if (g_turn_ev_set[d]) { (void)hipEventRecord(g_turn_ev[d], ctx->cur); g_turn_last[d] = ctx->cur; }
+        else (void)hipStreamSynchronize(ctx->cur);           // no event: hand over on the host
+        if (ctx->cur != ctx->stream) {                       // the rest of the call runs on a tail stream, behind what is queued
+            hipStream_t t = g_tail_stream[d][g_tail_next[d]++ & 1];
+            if (!t) t = ctx->stream;
+            (void)hipEventRecord(ctx->ev_turn, ctx->cur);
+            (void)hipStreamWaitEvent(t, ctx->ev_turn, 0);
+            ctx->cur = t;
+        }
         held = false; ctx->turn = nullptr;
         g_turn_mu[d].unlock();
     }
-    ~GpuTurn() { release(); }
+    ~GpuTurn() { release(); if (ctx) ctx->cur = ctx->stream; }
 };
 
 // background kernel launch (+ reduction of the raw sums; masked sums too when fused).
@@ -2061,31 +2145,31 @@ static int run_bg(pseg_ctx *ctx, const uint8_t *frames, int n_avail, int n_emit,
         if (ctx->bounds_n != n_avail || ctx->bounds_emit != n_emit || ctx->bounds_chunks != chunks || ctx->bounds_batch != batch_len ||
             ctx->bounds_tailk != tailk) {
             ENSURE(ctx->bounds, bnd.size() * 4);
-            HIPCHK(hipMemcpyAsync(ctx->bounds.p, bnd.data(), bnd.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-            HIPCHK(hipStreamSynchronize(ctx->stream));
+            HIPCHK(hipMemcpyAsync(ctx->bounds.p, bnd.data(), bnd.size() * 4, hipMemcpyHostToDevice, ctx->cur));
+            HIPCHK(hipStreamSynchronize(ctx->cur));
             ctx->bounds_n = n_avail; ctx->bounds_emit = n_emit; ctx->bounds_chunks = chunks; ctx->bounds_batch = batch_len;
             ctx->bounds_tailk = tailk;
         }
     }
-    HIPCHK(hipEventRecord(ctx->ev[0], ctx->stream));
+    HIPCHK(hipEventRecord(ctx->ev[0], ctx->cur));
     if (stream && P % 2048 == 0)
-        hipLaunchKernelGGL(k_bg_stream<false>, dim3(nfull + (nblk - nfull) * tailk, chunks), dim3(256), 0, ctx->stream, frames, P, cleaned,
+        hipLaunchKernelGGL(k_bg_stream<false>, dim3(nfull + (nblk - nfull) * tailk, chunks), dim3(256), 0, ctx->cur, frames, P, cleaned,
                            mask, thr, (uint8_t *)ctx->bits.p, (uint4 *)ctx->partials.p, (const int *)ctx->bounds.p, (uint8_t *)ctx->trash.p,
                            (uint32_t *)ctx->maskpart.p, (int)nfull, tailk);
     else if (stream)
-        hipLaunchKernelGGL(k_bg_stream<true>, dim3(nfull + (nblk - nfull) * tailk, chunks), dim3(256), 0, ctx->stream, frames, P, cleaned,
+        hipLaunchKernelGGL(k_bg_stream<true>, dim3(nfull + (nblk - nfull) * tailk, chunks), dim3(256), 0, ctx->cur, frames, P, cleaned,
                            mask, thr, (uint8_t *)ctx->bits.p, (uint4 *)ctx->partials.p, (const int *)ctx->bounds.p, (uint8_t *)ctx->trash.p,
                            (uint32_t *)ctx->maskpart.p, (int)nfull, tailk);
     else
         for (int c = 0; c < nbatch; c++) {                   // the re-reading kernel takes one batch per launch
             const size_t f0 = (size_t)c * (batch_len ? batch_len : 0);
             const int nc = batch_len ? ((c + 1) * batch_len < n_avail ? batch_len : last_len) : n;
-            hipLaunchKernelGGL(k_bg_generic, dim3(nblk, nc), dim3(256), 0, ctx->stream, frames + f0 * P, batch_len ? nc : n_kernel, NW, P,
+            hipLaunchKernelGGL(k_bg_generic, dim3(nblk, nc), dim3(256), 0, ctx->cur, frames + f0 * P, batch_len ? nc : n_kernel, NW, P,
                                cleaned + f0 * P, mask, thr, (uint8_t *)ctx->bits.p + f0 * (P / 8), (uint32_t *)ctx->partials.p + f0 * npart * 4);
         }
     HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
-    hipLaunchKernelGGL(k_reduce_partials, dim3(n), dim3(1024), 0, ctx->stream, (const uint32_t *)ctx->partials.p, (int)npart,
+    HIPCHK(hipEventRecord(ctx->ev[1], ctx->cur));
+    hipLaunchKernelGGL(k_reduce_partials, dim3(n), dim3(1024), 0, ctx->cur, (const uint32_t *)ctx->partials.p, (int)npart,
                        (unsigned long long)P, (unsigned long long *)ctx->fsums.p, (uint8_t *)ctx->valid_dev.p, 1, 0, 4,
                        (unsigned long long *)ctx->maskcnt.p, (uint32_t *)ctx->framebase.p + n + 1,
                        (const uint32_t *)ctx->maskpart.p, (stream && mask) ? (int)npart : 0,
@@ -2108,7 +2192,7 @@ static void finish_meanstd(const uint64_t *s, double cnt, double *mean, double *
 static int fetch_head(pseg_ctx *ctx)
 {
     HIPCHK(hipMemcpyAsync(ctx->pin_head.p, (const char *)ctx->head.p + ctx->head_copy_off, ctx->head_copy_bytes,
-                          hipMemcpyDeviceToHost, ctx->stream));
+                          hipMemcpyDeviceToHost, ctx->cur));
     return 0;
 }
 
@@ -2117,7 +2201,7 @@ static int fetch_raw_stats(pseg_ctx *ctx, int n, double *mean_std, uint8_t *vali
     if (!ctx->head_on_host) {
         int r = fetch_head(ctx);
         if (r) return r;
-        HIPCHK(hipStreamSynchronize(ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->cur));
     }
     HeadHost hh = head_host(ctx, n);
     for (int f = 0; f < n; f++) {
@@ -2210,7 +2294,6 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
 {
     const int H = ctx->H, W = ctx->W, WW = ctx->WW;
     const size_t P = ctx->P;
-    hipStream_t st = ctx->stream;
     SegState S;
     memset(&S, 0, sizeof(S));
     S.F = n; S.H = H; S.W = W; S.WW = WW;
@@ -2223,136 +2306,157 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
     uint32_t *ftot = (uint32_t *)ctx->ftot.p;            // [n] run totals | [3n] rank totals | [n+1] rowbase | [n+1] savedbase
     uint32_t *ftot3 = ftot + n, *rowbase = ftot3 + 3 * (size_t)n, *savedbase = rowbase + (n + 1);
 
-    HIPCHK(hipEventRecord(ctx->ev[2], st));
+    HIPCHK(hipEventRecord(ctx->ev[2], ctx->cur));
     // (the counters were cleared by k_reduce_partials; the mask pixels were counted by the background kernel when it ran fused)
     if (mask && !ctx->mask_counted)
-        hipLaunchKernelGGL(k_mask_count, dim3(1024), dim3(256), 0, st, mask, P, (unsigned long long *)ctx->maskcnt.p);
+        hipLaunchKernelGGL(k_mask_count, dim3(1024), dim3(256), 0, ctx->cur, mask, P, (unsigned long long *)ctx->maskcnt.p);
     const int runs_wpl = (S.WW + 3) / 4;                     // words per lane of k_runs_band
     const bool fused = !(ctx->runs_old || runs_wpl > 16);    // rows wider than 4096 px take the two-pass extraction (k_runs)
     const int nbpf = (H + BAND_H - 1) / BAND_H;
     uint32_t *bandmax_d = S.framebase + n + 1;
     unsigned long long *scan = (unsigned long long *)ctx->scan_state.p;
-    auto set_tables = [&]() {
+    const dim3 runs_grid(nblocks((size_t)n * H, 4 * RUNS_RPW));
+    RowsDev R;
+    int32_t *objlabel = nullptr, *objflag = nullptr, *saved_row = nullptr, *geo = nullptr;
+    unsigned long long *sz = nullptr;
+    long long *totals = (long long *)ctx->totals.p;
+    size_t rcap = 1;
+    // every table indexed by run (or by object: there are at most as many objects as runs) for `cap` runs
+    auto ensure_tables = [&](size_t cap) -> int {
+        const size_t nbgc = cap + (size_t)n * H;
+        ENSURE(ctx->run_x, cap * 4); ENSURE(ctx->run_fy, cap * 4); ENSURE(ctx->fg_parent, cap * 4); ENSURE(ctx->ext, cap * 4); ENSURE(ctx->gapl, cap * 4);
+        ENSURE(ctx->bg_parent, nbgc * 4); ENSURE(ctx->bg_left, nbgc * 4);
+        ENSURE(ctx->minx, cap * 4); ENSURE(ctx->maxx, cap * 4); ENSURE(ctx->maxy, cap * 4);
+        ENSURE(ctx->area2, cap * 4); ENSURE(ctx->extrank, cap * 4); ENSURE(ctx->keptrank, cap * 4); ENSURE(ctx->savedrank, cap * 4);
+        ENSURE(ctx->objlabel, cap * 4); ENSURE(ctx->objflag, cap * 4); ENSURE(ctx->runlabel, cap * 4);
+        ENSURE(ctx->rows, cap * 10 * 4);                     // rows: one per kept object; n_rows <= external roots <= runs
+        ENSURE(ctx->saved_row, cap * 4);
+        ENSURE(ctx->saved_geo, cap * 8 * 4 + cap * 3 * 8);
+        ENSURE(ctx->crop_off, (cap + 1) * 8); ENSURE(ctx->bits_off, (cap + 1) * 8); ENSURE(ctx->band_off, (cap + 1) * 8);
         S.run_x = (uint32_t *)ctx->run_x.p; S.run_fy = (uint32_t *)ctx->run_fy.p;
         S.fg_parent = (int32_t *)ctx->fg_parent.p; S.ext = (int32_t *)ctx->ext.p; S.gapl = (int32_t *)ctx->gapl.p;
         S.bg_parent = (int32_t *)ctx->bg_parent.p; S.bg_left = (int32_t *)ctx->bg_left.p;
         S.minx = (int32_t *)ctx->minx.p; S.maxx = (int32_t *)ctx->maxx.p; S.maxy = (int32_t *)ctx->maxy.p;
         S.area2 = (int32_t *)ctx->area2.p;
         S.extrank = (int32_t *)ctx->extrank.p; S.keptrank = (int32_t *)ctx->keptrank.p; S.savedrank = (int32_t *)ctx->savedrank.p;
+        objlabel = (int32_t *)ctx->objlabel.p; objflag = (int32_t *)ctx->objflag.p;
+        rcap = cap;
+        int32_t *rb_ = (int32_t *)ctx->rows.p;
+        R.frame = rb_; R.c = rb_ + rcap; R.label = rb_ + 2 * rcap; R.area2 = rb_ + 3 * rcap; R.x = rb_ + 4 * rcap; R.y = rb_ + 5 * rcap;
+        R.w = rb_ + 6 * rcap; R.h = rb_ + 7 * rcap; R.saved = rb_ + 8 * rcap; R.root = rb_ + 9 * rcap;
+        saved_row = (int32_t *)ctx->saved_row.p;
+        geo = (int32_t *)ctx->saved_geo.p;
+        sz = (unsigned long long *)(geo + 8 * rcap);
+        return 0;
     };
     auto launch_fused = [&](uint32_t capv) {
-        if (runs_wpl > 10) hipLaunchKernelGGL((k_runs_band<16>), dim3(nbpf * n), dim3(256), 0, st, S, runs_wpl, capv, scan, bandmax_d);
-        else hipLaunchKernelGGL((k_runs_band<10>), dim3(nbpf * n), dim3(256), 0, st, S, runs_wpl, capv, scan, bandmax_d);
-        if (H > BAND_H) hipLaunchKernelGGL(k_unions_rows, dim3((H - 1) / BAND_H, n), dim3(64), 0, st, S, BAND_H, capv, (const uint32_t *)bandmax_d);
+        if (runs_wpl > 10) hipLaunchKernelGGL((k_runs_band<16>), dim3(nbpf * n), dim3(256), 0, ctx->cur, S, runs_wpl, capv, scan, bandmax_d);
+        else hipLaunchKernelGGL((k_runs_band<10>), dim3(nbpf * n), dim3(256), 0, ctx->cur, S, runs_wpl, capv, scan, bandmax_d);
+        if (H > BAND_H) hipLaunchKernelGGL(k_unions_rows, dim3((H - 1) / BAND_H, n), dim3(64), 0, ctx->cur, S, BAND_H, capv, (const uint32_t *)bandmax_d);
     };
-    uint32_t spec_cap = 0;
-    const dim3 runs_grid(nblocks((size_t)n * H, 4 * RUNS_RPW));
-    if (fused) {
-        // One pass over the plane extracts, counts, scans and labels (k_runs_band), queued before the host knows the run count
-        // into the tables as they stand: capacity = what every table the kernel writes can hold
-        size_t c = ctx->run_x.bytes;
-        for (const DevBuf *b : {&ctx->run_fy, &ctx->fg_parent, &ctx->minx, &ctx->maxx, &ctx->maxy, &ctx->area2}) c = b->bytes < c ? b->bytes : c;
-        size_t cb = ctx->bg_parent.bytes < ctx->bg_left.bytes ? ctx->bg_parent.bytes : ctx->bg_left.bytes;
-        c /= 4; cb /= 4;
-        cb = cb > (size_t)n * H ? cb - (size_t)n * H : 0;
-        c = cb < c ? cb : c;
-        spec_cap = (uint32_t)(c > 0x3fffffffu ? 0x3fffffffu : c);
-        set_tables();
-        launch_fused(spec_cap);
-    } else {
-        hipLaunchKernelGGL(k_runs<false>, runs_grid, dim3(256), 0, st, S, n * H);
-        hipLaunchKernelGGL(k_scan_rows, dim3(n), dim3(256), 0, st, S, ftot, bandmax_d);
-        hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(256), 0, st, (const uint32_t *)ftot, S.framebase, n, 1, 1);
-        hipLaunchKernelGGL(k_rowoff_global, dim3(nblocks((size_t)n * (H + 1))), dim3(256), 0, st, S);
-    }
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(ctx->pin_nfg.p, S.framebase + n, 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync((char *)ctx->pin_nfg.p + 16, scan + 1, 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipEventRecord(ctx->ev[8], st));
-    HIPCHK(hipEventSynchronize(ctx->ev[8]));
-    const uint32_t nfg_u = ((const volatile uint32_t *)ctx->pin_nfg.p)[0], bandmax = ((const volatile uint32_t *)ctx->pin_nfg.p)[1];
-    if (fused && ((const volatile uint64_t *)ctx->pin_nfg.p)[2] != 0)
-        return fail(ctx, PSEG_ERR_HIP, "k_runs_band: a block waited for its predecessors' totals for too long");
-    if (nfg_u > 0x3fffffffu) return fail(ctx, PSEG_ERR_CAPACITY, "too many foreground runs");
-    const int nfg = (int)nfg_u, nbg = nfg + n * H;
-    const size_t cap = (size_t)(nfg > 0 ? nfg : 1);
-    ENSURE(ctx->run_x, cap * 4); ENSURE(ctx->run_fy, cap * 4); ENSURE(ctx->fg_parent, cap * 4); ENSURE(ctx->ext, cap * 4); ENSURE(ctx->gapl, cap * 4);
-    ENSURE(ctx->bg_parent, (size_t)nbg * 4); ENSURE(ctx->bg_left, (size_t)nbg * 4);
-    ENSURE(ctx->minx, cap * 4); ENSURE(ctx->maxx, cap * 4); ENSURE(ctx->maxy, cap * 4);
-    ENSURE(ctx->area2, cap * 4); ENSURE(ctx->extrank, cap * 4); ENSURE(ctx->keptrank, cap * 4); ENSURE(ctx->savedrank, cap * 4);
-    ENSURE(ctx->objlabel, cap * 4); ENSURE(ctx->objflag, cap * 4); ENSURE(ctx->runlabel, cap * 4);
-    set_tables();
-    int32_t *objlabel = (int32_t *)ctx->objlabel.p, *objflag = (int32_t *)ctx->objflag.p;
-
-    const bool runs_done = fused && spec_cap > 0 && nfg_u <= spec_cap;       // (the tables were not reallocated then: cap <= their size)
-    const bool bands_ok = bandmax <= BAND_CAP && !ctx->no_bands;
-    if (fused && !runs_done) {                               // the tables were too small (first batch, or a denser one): once more
-        HIPCHK(hipMemsetAsync(scan, 0, (size_t)scan_words(ctx, n) * 8, st));
-        launch_fused(0xffffffffu);
-    }
-    if (!fused) {
-        if (nfg > 0) hipLaunchKernelGGL(k_runs<true>, runs_grid, dim3(256), 0, st, S, n * H);
-        if (bands_ok) {
-            // bands of BAND_H rows are labelled in LDS; the global kernels only unite across the band boundaries
-            hipLaunchKernelGGL(k_band_label, dim3(nbpf, n), dim3(256), 0, st, S);
-            if (H > BAND_H) hipLaunchKernelGGL(k_unions_rows, dim3((H - 1) / BAND_H, n), dim3(64), 0, st, S, BAND_H, 0xffffffffu, (const uint32_t *)bandmax_d);
+    // from the flattening to the size scans; gridded for `runs` runs, guarded by (cap, bcap) on the device
+    auto launch_chain = [&](size_t runs, uint32_t capv, uint32_t bcap) {
+        const size_t nbgr = runs + (size_t)n * H;
+        hipLaunchKernelGGL(k_flatten_resolve, dim3(nblocks(nbgr)), dim3(256), 0, ctx->cur, S, capv, bcap);
+        if (runs > 0) {
+            hipLaunchKernelGGL(k_bbox, dim3(nblocks(runs)), dim3(256), 0, ctx->cur, S, capv, bcap);
+            hipLaunchKernelGGL(k_area, dim3(nblocks(runs)), dim3(256), 0, ctx->cur, S, capv, bcap);
         }
-    }
-    if (!bands_ok) {                                         // frames too dense for the LDS tables (or PSEG_NO_BANDS): global union-find
-        hipLaunchKernelGGL(k_init, dim3(nblocks(nbg)), dim3(256), 0, st, S, nfg, nbg);
-        hipLaunchKernelGGL(k_unions, dim3(nblocks(nbg)), dim3(256), 0, st, S, nfg, nbg, 0);
-    }
-    hipLaunchKernelGGL(k_flatten_resolve, dim3(nblocks(nbg)), dim3(256), 0, st, S, nfg, nbg);
-    if (nfg > 0) {
-        hipLaunchKernelGGL(k_bbox, dim3(nblocks(nfg)), dim3(256), 0, st, S, nfg);
-        hipLaunchKernelGGL(k_area, dim3(nblocks(nfg)), dim3(256), 0, st, S, nfg);
-    }
-    hipLaunchKernelGGL(k_rank, dim3(n), dim3(1024), 0, st, S, min_seg, min_save, ftot3);
-    hipLaunchKernelGGL(k_scan_small, dim3(2), dim3(256), 0, st, (const uint32_t *)(ftot3 + 1), rowbase, n, 3, 1);   // rowbase | savedbase
-    HIPCHK(hipGetLastError());
-    // rows: one per kept object; n_rows <= external roots <= nfg bounds the buffers without a host round trip
-    const size_t rcap = cap, scap = cap;
-    ENSURE(ctx->rows, rcap * 10 * 4);
-    ENSURE(ctx->saved_row, scap * 4);
-    ENSURE(ctx->saved_geo, scap * 8 * 4 + scap * 3 * 8);
-    ENSURE(ctx->crop_off, (scap + 1) * 8);
-    ENSURE(ctx->bits_off, (scap + 1) * 8);
-    ENSURE(ctx->band_off, (scap + 1) * 8);
-    RowsDev R;
-    {
-        int32_t *b = (int32_t *)ctx->rows.p;
-        R.frame = b; R.c = b + rcap; R.label = b + 2 * rcap; R.area2 = b + 3 * rcap; R.x = b + 4 * rcap; R.y = b + 5 * rcap;
-        R.w = b + 6 * rcap; R.h = b + 7 * rcap; R.saved = b + 8 * rcap; R.root = b + 9 * rcap;
-    }
-    int32_t *saved_row = (int32_t *)ctx->saved_row.p;
-    int32_t *geo = (int32_t *)ctx->saved_geo.p;
-    unsigned long long *sz = (unsigned long long *)(geo + 8 * scap);
-    long long *totals = (long long *)ctx->totals.p;
-    if (nfg > 0) {
-        hipLaunchKernelGGL(k_emit, dim3(nblocks(nfg)), dim3(256), 0, st, S, nfg, min_seg, min_save, (const uint32_t *)ftot3,
-                           (const uint32_t *)rowbase, (const uint32_t *)savedbase, R, objlabel, objflag, saved_row,
-                           (int32_t *)ctx->runlabel.p);
-        hipLaunchKernelGGL(k_saved_geo, dim3(nblocks(nfg)), dim3(256), 0, st, (const uint32_t *)(savedbase + n),
-                           (const int32_t *)saved_row, R, geo, sz, totals);
-    }
-    hipLaunchKernelGGL(k_scan_sizes, dim3(1), dim3(1024), 0, st, (const unsigned long long *)sz, (const uint32_t *)(savedbase + n),
-                       (long long *)ctx->crop_off.p, (long long *)ctx->bits_off.p, (long long *)ctx->band_off.p, totals);
-    HIPCHK(hipGetLastError());
-    // per-frame tables and totals to the host (one copy of the head arena); the label map is written while the host waits
-    { int r_ = fetch_head(ctx); if (r_) return r_; }
-    HIPCHK(hipEventRecord(ctx->ev[3], st));
-    // (running the label fill on a second stream next to the crop / property kernels was measured: the fill takes 2.0 ms
-    // instead of 0.93 ms when it shares the CUs, a net loss)
-    if (labels) {
-        hipLaunchKernelGGL(k_label_fill, dim3((W + 1023) / 1024, H, n), dim3(256), 0, st, S,
-                           (const int32_t *)ctx->runlabel.p, labels);
+        hipLaunchKernelGGL(k_rank, dim3(n), dim3(1024), 0, ctx->cur, S, min_seg, min_save, ftot3, capv, bcap);
+        hipLaunchKernelGGL(k_scan_small, dim3(2), dim3(256), 0, ctx->cur, (const uint32_t *)(ftot3 + 1), rowbase, n, 3, 1);   // rowbase | savedbase
+        if (runs > 0) {
+            hipLaunchKernelGGL(k_emit, dim3(nblocks(runs)), dim3(256), 0, ctx->cur, S, capv, bcap, min_seg, min_save, (const uint32_t *)ftot3,
+                               (const uint32_t *)rowbase, (const uint32_t *)savedbase, R, objlabel, objflag, saved_row,
+                               (int32_t *)ctx->runlabel.p);
+            hipLaunchKernelGGL(k_saved_geo, dim3(nblocks(runs)), dim3(256), 0, ctx->cur, S, capv, bcap, (const uint32_t *)(savedbase + n),
+                               (const int32_t *)saved_row, R, geo, sz);
+        }
+        hipLaunchKernelGGL(k_scan_sizes, dim3(1), dim3(1024), 0, ctx->cur, S, capv, bcap, (const unsigned long long *)sz,
+                           (const uint32_t *)(savedbase + n), (long long *)ctx->crop_off.p, (long long *)ctx->bits_off.p,
+                           (long long *)ctx->band_off.p, totals);
+    };
+    // Fast path: the whole chain is queued at once, sized by the tables' capacity (what the largest batch so far needed plus a
+    // quarter); the host looks at the totals only when the head arrives, behind the label fill.  Slow path (first batch, a
+    // denser batch, bands beyond the LDS labelling, very wide rows): totals first, then the chain.
+    bool spec = fused && !ctx->no_bands && ctx->runcap > 0 && ctx->spec_hold == 0;
+    if (ctx->spec_hold > 0) ctx->spec_hold--;
+    bool turn_released = false;
+    int nfg = 0;
+    for (;;) {
+        if (spec) {
+            { int r_ = ensure_tables(ctx->runcap); if (r_) return r_; }
+            launch_fused((uint32_t)ctx->runcap);
+            launch_chain(ctx->runcap, (uint32_t)ctx->runcap, BAND_CAP);
+        } else {
+            { int r_ = ensure_tables(ctx->runcap > 0 ? ctx->runcap : 1); if (r_) return r_; }
+            const uint32_t cap0 = fused && ctx->runcap > 0 ? (uint32_t)ctx->runcap : 0u;
+            if (fused) {
+                launch_fused(cap0);
+            } else {
+                hipLaunchKernelGGL(k_runs<false>, runs_grid, dim3(256), 0, ctx->cur, S, n * H);
+                hipLaunchKernelGGL(k_scan_rows, dim3(n), dim3(256), 0, ctx->cur, S, ftot, bandmax_d);
+                hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(256), 0, ctx->cur, (const uint32_t *)ftot, S.framebase, n, 1, 1);
+                hipLaunchKernelGGL(k_rowoff_global, dim3(nblocks((size_t)n * (H + 1))), dim3(256), 0, ctx->cur, S);
+            }
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(ctx->pin_nfg.p, S.framebase + n, 12, hipMemcpyDeviceToHost, ctx->cur));
+            HIPCHK(hipEventRecord(ctx->ev[8], ctx->cur));
+            HIPCHK(hipEventSynchronize(ctx->ev[8]));
+            const uint32_t nfg_u = ((const volatile uint32_t *)ctx->pin_nfg.p)[0], bandmax = ((const volatile uint32_t *)ctx->pin_nfg.p)[1];
+            if (fused && ((const volatile uint32_t *)ctx->pin_nfg.p)[2] != 0)
+                return fail(ctx, PSEG_ERR_HIP, "k_runs_band: a block waited for its predecessors' totals for too long");
+            if (nfg_u > 0x3fffffffu) return fail(ctx, PSEG_ERR_CAPACITY, "too many foreground runs");
+            nfg = (int)nfg_u;
+            const bool fits = fused && cap0 > 0 && nfg_u <= cap0;
+            if ((size_t)nfg > ctx->runcap || ctx->runcap == 0) ctx->runcap = (size_t)nfg + (size_t)nfg / 4 + 1024;
+            { int r_ = ensure_tables(ctx->runcap); if (r_) return r_; }
+            const bool bands_ok = bandmax <= BAND_CAP && !ctx->no_bands;
+            if (fused && !fits) {                            // the tables were too small: once more
+                HIPCHK(hipMemsetAsync(scan, 0, (size_t)scan_words(ctx, n) * 8, ctx->cur));
+                launch_fused(0xffffffffu);
+            }
+            if (!fused) {
+                if (nfg > 0) hipLaunchKernelGGL(k_runs<true>, runs_grid, dim3(256), 0, ctx->cur, S, n * H);
+                if (bands_ok) {
+                    // bands of BAND_H rows are labelled in LDS; the global kernels only unite across the band boundaries
+                    hipLaunchKernelGGL(k_band_label, dim3(nbpf, n), dim3(256), 0, ctx->cur, S);
+                    if (H > BAND_H) hipLaunchKernelGGL(k_unions_rows, dim3((H - 1) / BAND_H, n), dim3(64), 0, ctx->cur, S, BAND_H, 0xffffffffu, (const uint32_t *)bandmax_d);
+                }
+            }
+            if (!bands_ok) {                                 // frames too dense for the LDS tables (or PSEG_NO_BANDS): global union-find
+                const int nbg = nfg + n * H;
+                hipLaunchKernelGGL(k_init, dim3(nblocks(nbg)), dim3(256), 0, ctx->cur, S, nfg, nbg);
+                hipLaunchKernelGGL(k_unions, dim3(nblocks(nbg)), dim3(256), 0, ctx->cur, S, nfg, nbg, 0);
+            }
+            launch_chain((size_t)nfg, 0xffffffffu, 0xffffffffu);
+        }
         HIPCHK(hipGetLastError());
+        // per-frame tables and totals to the host (one copy of the head arena); the label map is written while the host waits
+        { int r_ = fetch_head(ctx); if (r_) return r_; }
+        HIPCHK(hipEventRecord(ctx->ev[3], ctx->cur));
+        // (running the label fill on a second stream next to the crop / property kernels was measured: the fill takes 2.0 ms
+        // instead of 0.93 ms when it shares the CUs, a net loss)
+        if (labels) {
+            hipLaunchKernelGGL(k_label_fill, dim3((W + 1023) / 1024, H, n), dim3(256), 0, ctx->cur, S,
+                               (const int32_t *)ctx->runlabel.p, labels, spec ? (uint32_t)ctx->runcap : 0xffffffffu, spec ? (uint32_t)BAND_CAP : 0xffffffffu);
+            HIPCHK(hipGetLastError());
+        }
+        HIPCHK(hipEventRecord(ctx->ev[4], ctx->cur));
+        // The streaming kernels of this batch are queued.  What follows (crops, properties, hulls) waits on memory latency and
+        // fills neither the vector units nor the memory system: the next batch's background kernel may run beside it.
+        if (ctx->turn && ctx->early_release && !turn_released) { ctx->turn->release(); turn_released = true; }
+        HIPCHK(hipEventSynchronize(ctx->ev[3]));
+        if (!spec) break;
+        const HeadHost h0 = head_host(ctx, n);
+        if (h0.totals[6] != 0) return fail(ctx, PSEG_ERR_HIP, "k_runs_band: a block waited for its predecessors' totals for too long");
+        if ((unsigned long long)h0.totals[4] > 0x3fffffffull) return fail(ctx, PSEG_ERR_CAPACITY, "too many foreground runs");
+        nfg = (int)h0.totals[4];
+        if ((size_t)nfg <= ctx->runcap && h0.totals[5] <= BAND_CAP) break;       // the chain ran
+        // it did not: more runs than the tables hold, or a band beyond the LDS labelling -- repeat, totals first
+        if (h0.totals[5] > BAND_CAP) ctx->spec_hold = 16;    // dense frames come in stretches: straight to the slow path for a while
+        spec = false;
+        HIPCHK(hipMemsetAsync(scan, 0, (size_t)scan_words(ctx, n) * 8, ctx->cur));
     }
-    HIPCHK(hipEventRecord(ctx->ev[4], st));
-    // The streaming kernels of this batch are queued.  What follows (crops, properties, hulls) waits on memory latency and
-    // fills neither the vector units nor the memory system: the next batch's background kernel may run beside it.
-    if (ctx->turn && ctx->early_release) ctx->turn->release();
-    HIPCHK(hipEventSynchronize(ctx->ev[3]));
     ctx->head_on_host = true;
     const HeadHost hh = head_host(ctx, n);
     const uint32_t *h_ftot3 = hh.ftot3, *h_rowbase = hh.rowbase, *h_savedbase = hh.savedbase;
@@ -2371,9 +2475,9 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
         ENSURE(ctx->crops_raw, (size_t)h_tot[0]); ENSURE(ctx->crops_masked, (size_t)h_tot[0]); ENSURE(ctx->crops_mask, (size_t)h_tot[0]);
         ENSURE(ctx->maskbits, (size_t)h_tot[1] * 2 * 4);     // first / last column of every window row (convex hull input)
         ENSURE(ctx->band_obj, (size_t)h_tot[2] * 4);
-        hipLaunchKernelGGL(k_band_map, dim3(nblocks((size_t)n_saved, 4)), dim3(256), 0, st, n_saved, (const long long *)ctx->band_off.p,
+        hipLaunchKernelGGL(k_band_map, dim3(nblocks((size_t)n_saved, 4)), dim3(256), 0, ctx->cur, n_saved, (const long long *)ctx->band_off.p,
                            (int32_t *)ctx->band_obj.p, d_sums);
-        hipLaunchKernelGGL(k_crops_sums<false>, dim3((unsigned)h_tot[2]), dim3(CROP_THREADS), 0, st, S, n_saved, (const int32_t *)geo,
+        hipLaunchKernelGGL(k_crops_sums<false>, dim3((unsigned)h_tot[2]), dim3(CROP_THREADS), 0, ctx->cur, S, n_saved, (const int32_t *)geo,
                            (const long long *)ctx->crop_off.p, (const long long *)ctx->band_off.p, (const int32_t *)objflag,
                            cleaned, raw, (uint8_t *)ctx->crops_raw.p, (uint8_t *)ctx->crops_masked.p,
                            (uint8_t *)ctx->crops_mask.p, d_sums, (const long long *)ctx->bits_off.p,
@@ -2387,14 +2491,14 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
         if (hmax > 2700) return fail(ctx, PSEG_ERR_CAPACITY, "saved object too tall for the convex-hull kernel (limit 2700 rows)");
         if (lds_big > 48 * 1024)
             HIPCHK(hipFuncSetAttribute((const void *)k_convex, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big));
-        hipLaunchKernelGGL(k_convex, dim3(n_saved), dim3(128), lds_small, st, n_saved, (const int32_t *)geo,
+        hipLaunchKernelGGL(k_convex, dim3(n_saved), dim3(128), lds_small, ctx->cur, n_saved, (const int32_t *)geo,
                            (const long long *)ctx->bits_off.p, (const int32_t *)ctx->maskbits.p, d_sums, 0, hsmall);
         if (hmax > hsmall)
-            hipLaunchKernelGGL(k_convex, dim3(n_saved), dim3(128), lds_big, st, n_saved, (const int32_t *)geo,
+            hipLaunchKernelGGL(k_convex, dim3(n_saved), dim3(128), lds_big, ctx->cur, n_saved, (const int32_t *)geo,
                                (const long long *)ctx->bits_off.p, (const int32_t *)ctx->maskbits.p, d_sums, hsmall, hmax);
         HIPCHK(hipGetLastError());
     }
-    HIPCHK(hipEventRecord(ctx->ev[5], st));
+    HIPCHK(hipEventRecord(ctx->ev[5], ctx->cur));
     ctx->crop_bytes = h_tot[0];
     ctx->n_saved = n_saved;
 
@@ -2404,15 +2508,16 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
     int32_t *hrows = (int32_t *)(hp + o_rows), *h_saved_row = (int32_t *)(hp + o_srow);
     h_crop_off[0] = 0;
     if (n_rows > 0) {
-        hipLaunchKernelGGL(k_pack_out, dim3(nblocks((size_t)n_rows + 1)), dim3(256), 0, st, (const int32_t *)ctx->rows.p, rcap, n_rows,
+        hipLaunchKernelGGL(k_pack_out, dim3(nblocks((size_t)n_rows + 1)), dim3(256), 0, ctx->cur, (const int32_t *)ctx->rows.p, rcap, n_rows,
                            (const int32_t *)saved_row, (const long long *)ctx->crop_off.p, n_saved,
                            (int32_t *)((char *)ctx->outpack.p + o_rows), (int32_t *)((char *)ctx->outpack.p + o_srow),
                            (long long *)((char *)ctx->outpack.p + o_coff));
         HIPCHK(hipGetLastError());
     }
     if (ctx->turn) ctx->turn->release();                    // last kernel queued: the next batch may follow it on the GPU
-    if (n_rows > 0) HIPCHK(hipMemcpyAsync(hp, ctx->outpack.p, o_bytes, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    if (n_rows > 0) HIPCHK(hipMemcpyAsync(hp, ctx->outpack.p, o_bytes, hipMemcpyDeviceToHost, ctx->cur));
+    HIPCHK(hipEventRecord(ctx->ev[8], ctx->cur));           // (an event, not the stream: other contexts' tails share it)
+    HIPCHK(hipEventSynchronize(ctx->ev[8]));
     HIPCHK(hipEventElapsedTime(&ctx->ms[2], ctx->ev[2], ctx->ev[3]));
     HIPCHK(hipEventElapsedTime(&ctx->ms[3], ctx->ev[3], ctx->ev[4]));
     HIPCHK(hipEventElapsedTime(&ctx->ms[4], ctx->ev[4], ctx->ev[5]));
@@ -2469,15 +2574,15 @@ extern "C" int pseg_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t 
     ENSURE(ctx->partials, (size_t)n * nblk * 4 * sizeof(uint32_t));
     { int r_ = head_setup(ctx, n); if (r_) return r_; }
     GpuTurn turn(ctx);
-    HIPCHK(hipEventRecord(ctx->ev[6], ctx->stream));
-    if (valid) HIPCHK(hipMemcpyAsync(ctx->valid_dev.p, valid, n, hipMemcpyHostToDevice, ctx->stream));
-    else HIPCHK(hipMemsetAsync(ctx->valid_dev.p, 1, n, ctx->stream));
-    HIPCHK(hipEventRecord(ctx->ev[0], ctx->stream));
-    hipLaunchKernelGGL(k_threshold, dim3(nblk, n), dim3(256), 0, ctx->stream, cleaned, P, mask, threshold, (uint8_t *)ctx->bits.p,
+    HIPCHK(hipEventRecord(ctx->ev[6], ctx->cur));
+    if (valid) HIPCHK(hipMemcpyAsync(ctx->valid_dev.p, valid, n, hipMemcpyHostToDevice, ctx->cur));
+    else HIPCHK(hipMemsetAsync(ctx->valid_dev.p, 1, n, ctx->cur));
+    HIPCHK(hipEventRecord(ctx->ev[0], ctx->cur));
+    hipLaunchKernelGGL(k_threshold, dim3(nblk, n), dim3(256), 0, ctx->cur, cleaned, P, mask, threshold, (uint8_t *)ctx->bits.p,
                        (uint32_t *)ctx->partials.p);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
-    hipLaunchKernelGGL(k_reduce_partials, dim3(n), dim3(1024), 0, ctx->stream, (const uint32_t *)ctx->partials.p, (int)nblk,
+    HIPCHK(hipEventRecord(ctx->ev[1], ctx->cur));
+    hipLaunchKernelGGL(k_reduce_partials, dim3(n), dim3(1024), 0, ctx->cur, (const uint32_t *)ctx->partials.p, (int)nblk,
                        (unsigned long long)P, (unsigned long long *)ctx->fsums.p, (uint8_t *)ctx->valid_dev.p, 0, 2, 2,
                        (unsigned long long *)ctx->maskcnt.p, (uint32_t *)ctx->framebase.p + n + 1, (const uint32_t *)nullptr, 0,
                        (unsigned long long *)ctx->scan_state.p, scan_words(ctx, n));
@@ -2485,8 +2590,8 @@ extern "C" int pseg_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t 
     HIPCHK(hipGetLastError());
     r = run_detect(ctx, cleaned, raw, mask, n, min_area_to_segment, min_area_to_save, labels, out);
     if (r) return r;
-    HIPCHK(hipEventRecord(ctx->ev[7], ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipEventRecord(ctx->ev[7], ctx->cur));
+    HIPCHK(hipEventSynchronize(ctx->ev[7]));
     HIPCHK(hipEventElapsedTime(&ctx->ms[1], ctx->ev[0], ctx->ev[1]));
     HIPCHK(hipEventElapsedTime(&ctx->ms[5], ctx->ev[6], ctx->ev[7]));
     ctx->ms[0] = 0;
@@ -2503,12 +2608,12 @@ static int process_impl(pseg_ctx *ctx, const uint8_t *frames, int n_avail, int n
     if (n_emit < 1 || n_emit > n_avail) return fail(ctx, PSEG_ERR_ARG, "n_emit out of range");
     const int n = n_emit;
     GpuTurn turn(ctx);
-    HIPCHK(hipEventRecord(ctx->ev[6], ctx->stream));
+    HIPCHK(hipEventRecord(ctx->ev[6], ctx->cur));
     r = run_bg(ctx, frames, n_avail, n_emit, n_bg_imgs, mask, threshold, cleaned, batch_len);
     if (r) return r;
     r = run_detect(ctx, cleaned, cleaned, mask, n, min_area_to_segment, min_area_to_save, labels, out);
     if (r) return r;
-    HIPCHK(hipEventRecord(ctx->ev[7], ctx->stream));
+    HIPCHK(hipEventRecord(ctx->ev[7], ctx->cur));
     r = fetch_raw_stats(ctx, n, mean_std, valid);
     if (r) return r;
     HIPCHK(hipEventSynchronize(ctx->ev[7]));
