@@ -9,8 +9,18 @@ import json
 import sys
 from collections import defaultdict
 
-GROUP = {"k_bg_stream": "bg_correct", "k_label_fill": "label_map", "k_run_labels": "label_map",
-         "k_crops_sums<false>": "crops_props", "k_convex": "crops_props", "k_band_map": "crops_props", "k_pack_out": "crops_props"}
+# kernel name prefix -> group (template arguments vary: k_bg_stream<false>, k_runs_band<10>, ...); everything else that starts
+# with k_ belongs to the sparse labelling chain
+PREFIX = [("k_bg_stream", "bg_correct"), ("k_bg_generic", "bg_correct"), ("k_label_fill", "label_map"),
+          ("k_crops_sums", "crops_props"), ("k_convex", "crops_props"), ("k_band_map", "crops_props"), ("k_pack_out", "crops_props")]
+SKIP = ("k_synth", "k_fill_spans", "__amd", "k_reduce_partials", "k_mask_count")
+
+
+def group_of(kernel):
+    for pre, g in PREFIX:
+        if kernel.startswith(pre):
+            return g
+    return "sparse_labelling" if kernel.startswith("k_") else None
 
 
 def per_kernel(path, counter):
@@ -34,8 +44,8 @@ def main():
         rd = fetch.get(k, 0.0) * 1024 * 2          # KB -> B, gfx950 read correction x2
         wr = write.get(k, 0.0) * 1024
         kernels[k] = {"read_bytes": rd, "write_bytes": wr, "launches_sampled": nf.get(k, 0)}
-        g = GROUP.get(k, "sparse_labelling")
-        if k.startswith("k_synth") or k.startswith("k_fill_spans") or k.startswith("__amd") or k.startswith("k_reduce_partials"):
+        g = group_of(k)
+        if g is None or k.startswith(SKIP):
             continue
         groups[g] += rd + wr
     out = dict(groups)
