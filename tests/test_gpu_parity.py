@@ -486,3 +486,33 @@ def test_switches_do_not_change_results(monkeypatch, env):
         helpers.compare_table(res[k][0], dets, H, W, labels=res[k][1])
     for s in segs:
         s.close()
+
+
+def test_known_answer_frames(gpu_seg_factory):
+    """The hand-derived cases of tests/test_oracle_contours.py (hollow diamond, corner contact, spur, ring in ring, the
+    L-shaped object whose window shows an earlier object's fill) through the HIP path."""
+    import torch
+    H, W = 128, 192
+    seg = gpu_seg_factory(H, W)
+    fr = []
+
+    def blank():
+        return np.full((H, W), 255, np.uint8)
+    a = blank(); a[4, 6] = a[6, 6] = a[5, 5] = a[5, 7] = 40; a[20:23, 20:23] = 10; a[23:26, 23:26] = 10
+    a[43:47, 43:47] = 90; a[44, 47:52] = 90; fr.append(a)              # hollow diamond, corner contact, spur
+    a = blank(); a[1:23, 1:23] = 30; a[3:21, 3:21] = 255; a[5:19, 5:19] = 30; a[7:17, 7:17] = 255; a[10:13, 10:13] = 30
+    fr.append(a)                                                       # ring > ring > blob: one object
+    a = blank(); a[10:100, 10:20] = 50; a[10:20, 10:150] = 50; a[40:70, 60:100] = 80; a[75:80, 15:70] = 120
+    fr.append(a)                                                       # cumulative mask (detection.py:206,245)
+    cleaned = np.stack(fr)
+    n = len(fr)
+    items = [(cleaned[f], cleaned[f], [100.0, 50.0], f"k_{f:03d}.png") for f in range(n)]
+    for min_seg, min_save in ((1, 5), (10, 400)):
+        dets = helpers.oracle_detect(items, None, min_area_to_segment=min_seg, min_area_to_save=min_save, mask_img=False)
+        labels = torch.empty((n, H, W), dtype=torch.int32, device="cuda")
+        tab = seg.detect(torch.from_numpy(cleaned).cuda(), min_area_to_segment=min_seg, min_area_to_save=min_save, labels=labels,
+                         fetch_crops=True)
+        helpers.compare_table(tab, dets, H, W, labels=labels.cpu().numpy())
+    assert sorted(tab.area[tab.frame == 2].tolist()) == [39.0 * 29.0, 12355.0] or len(tab.area[tab.frame == 2]) == 2
+    dets = helpers.oracle_detect(items, None, min_area_to_segment=1, min_area_to_save=5, mask_img=False)
+    assert sorted(r[6] for r in dets[0]["rows"]) == [2.0, 8.0, 10.0] and [r[6] for r in dets[1]["rows"]] == [441.0]

@@ -128,3 +128,69 @@ def test_circle_is_symmetric_and_monotone():
         yy, xx = np.nonzero(b)
         d2 = (yy - c) ** 2 + (xx - c) ** 2
         assert d2.max() <= (r + 0.5) ** 2 + 1 and (~b[(np.mgrid[0:m.shape[0], 0:m.shape[1]][0] - c) ** 2 + (np.mgrid[0:m.shape[0], 0:m.shape[1]][1] - c) ** 2 <= (r - 1) ** 2]).sum() == 0
+
+
+def test_more_known_answers():
+    """further hand-derived cases of SURVEY.md 8(c): hollow diamond, diagonal contact, spur, ring in ring"""
+    img = np.zeros((12, 16), np.uint8)
+    img[4, 6] = img[6, 6] = img[5, 5] = img[5, 7] = 255                             # diamond ring, centre empty
+    cs = contours(img)
+    assert len(cs) == 1 and cv.contourArea(cs[0]) == 2.0 and cv.boundingRect(cs[0]) == (5, 4, 3, 3)
+    m = np.zeros_like(img)
+    cv.drawContours(m, cs, -1, 255, cv.FILLED)
+    assert m[5, 6] == 255 and m.sum() == 5 * 255          # the centre is enclosed (background is 4-connected): filled
+    img[:] = 0
+    img[2:5, 2:5] = 255
+    img[5:8, 5:8] = 255                                   # two squares touching at a corner: ONE 8-connected object
+    cs = contours(img)
+    assert len(cs) == 1 and cv.boundingRect(cs[0]) == (2, 2, 6, 6)
+    assert cv.contourArea(cs[0]) == 8.0                   # two 2 x 2 polygons of pixel centres; the diagonal link adds nothing
+    assert cs[0].reshape(-1, 2).tolist() == [[2, 2], [2, 4], [4, 4], [5, 5], [5, 7], [7, 7], [7, 5], [5, 5], [4, 4], [4, 2]]
+    img[:] = 0
+    img[3:7, 3:7] = 255
+    img[4, 7:12] = 255                                    # a 1-pixel spur: traversed out and back, zero area of its own;
+    (c,) = contours(img)                                  # the border cuts the two corners at its foot diagonally: + 2 x 1/2
+    assert cv.contourArea(c) == 9.0 + 1.0 and cv.boundingRect(c) == (3, 3, 9, 4)
+    assert c.reshape(-1, 2).tolist() == [[3, 3], [3, 6], [6, 6], [6, 5], [7, 4], [11, 4], [7, 4], [6, 3]]
+    img = np.zeros((24, 24), np.uint8)
+    img[1:23, 1:23] = 255; img[3:21, 3:21] = 0            # ring
+    img[5:19, 5:19] = 255; img[7:17, 7:17] = 0            # ring inside its hole: not external
+    img[10:13, 10:13] = 255                               # blob inside the inner ring's hole: not external either
+    cs = contours(img)
+    assert len(cs) == 1 and cv.contourArea(cs[0]) == 21.0 * 21.0
+    lab = cv.label_map(img, cs)
+    assert lab[1, 1] == 1 and lab[5, 5] == 0 and lab[11, 11] == 0
+    m = np.zeros_like(img)
+    cv.drawContours(m, cs, -1, 255, cv.FILLED)
+    assert (m[1:23, 1:23] == 255).all() and m.sum() == 22 * 22 * 255
+
+
+def test_cumulative_mask_and_iteration_order():
+    """detection.py:206,222,245-246: ONE mask per frame collects the FILLED contours of the saved objects in iteration order
+    (OpenCV's: last found first).  Object A lies inside the bounding box of the L-shaped object B and below B's first
+    pixel, so A is iterated first (c = 0): A's mask window shows A alone although B's bar crosses A's bounding box... no: B
+    is not drawn yet; B's window (c = 1) also shows A's fill."""
+    from oracle import pipeline_ref as ref
+    H, W = 120, 160
+    cleaned = np.full((H, W), 255, np.uint8)
+    cleaned[10:100, 10:20] = 50                           # B: vertical bar ...
+    cleaned[10:20, 10:150] = 50                           # ... and horizontal bar (an L turned upside down); first pixel (10, 10)
+    cleaned[40:70, 60:100] = 80                           # A: 40 x 30 block inside B's bounding box; first pixel (40, 60)
+    cleaned[75:80, 15:70] = 120                           # C: a thin bar touching nothing... it touches B's vertical bar: part of B
+    det = ref.detect_on_img((cleaned, cleaned, [100.0, 50.0], "f_0001.png"), None, mask_img=False)
+    rows, crops = det["rows"], {c[0]: c for c in det["crops"]}
+    assert [r[0] for r in rows] == [0, 1] and [r[11] for r in rows] == [1, 1]
+    # c = 0 is A (found last), c = 1 is B (+ the bar C joined to it)
+    assert tuple(rows[0][7:11]) == (60, 40, 40, 30) and rows[0][6] == 39.0 * 29.0
+    assert tuple(rows[1][7:11]) == (10, 10, 140, 90)
+    _, masked_a, raw_a, mask_a = crops[0]
+    _, masked_b, raw_b, mask_b = crops[1]
+    assert (mask_a == 255).all()                          # A alone (C's bar ends at x = 69, y 75..79: outside A's box)
+    assert mask_b.shape == (90, 140)
+    assert (mask_b[30:60, 50:90] == 255).all()            # A's fill inside B's window: drawn one iteration earlier
+    want_b = np.zeros((90, 140), bool)
+    want_b[0:90, 0:10] = True; want_b[0:10, 0:140] = True; want_b[65:70, 5:60] = True; want_b[30:60, 50:90] = True
+    assert np.array_equal(mask_b == 255, want_b)
+    assert np.array_equal(masked_b, np.where(want_b, cleaned[10:100, 10:150], 255))
+    assert rows[1][12 + 5] == want_b.sum()                # area_exc of B's row counts A's pixels too (regionprops of the window)
+    assert np.array_equal(raw_b, cleaned[10:100, 10:150])
