@@ -513,6 +513,6 @@ def test_known_answer_frames(gpu_seg_factory):
         tab = seg.detect(torch.from_numpy(cleaned).cuda(), min_area_to_segment=min_seg, min_area_to_save=min_save, labels=labels,
                          fetch_crops=True)
         helpers.compare_table(tab, dets, H, W, labels=labels.cpu().numpy())
-    assert sorted(tab.area[tab.frame == 2].tolist()) == [39.0 * 29.0, 12355.0] or len(tab.area[tab.frame == 2]) == 2
+    assert len(tab.area[tab.frame == 2]) == 2
     dets = helpers.oracle_detect(items, None, min_area_to_segment=1, min_area_to_save=5, mask_img=False)
     assert sorted(r[6] for r in dets[0]["rows"]) == [2.0, 8.0, 10.0] and [r[6] for r in dets[1]["rows"]] == [441.0]
