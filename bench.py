@@ -67,6 +67,8 @@ def main():
     ap.add_argument("--single-device", action="store_true", help="every rank uses cuda:0 (rehearsal only; never a measurement)")
     ap.add_argument("--streams", type=int, default=3, help="contexts (own HIP stream each) that alternate library calls")
     ap.add_argument("--driver", default="submit", choices=["submit", "threads"])
+    ap.add_argument("--force-dist", action="store_true", help="run the N > 1 code path (frame ranges, process group, table gathers on "
+                    "their thread) with a world of one rank: all a one-GPU box allows through RCCL")
     ap.add_argument("--host-batches", type=int, default=6, help="batches of the host-input measurement (0 = skip)")
     args = ap.parse_args()
 
@@ -85,8 +87,12 @@ def main():
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
-    if world > 1:
+    dist_on = world > 1 or args.force_dist
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
         else:
@@ -95,7 +101,7 @@ def main():
     dev = f"cuda:{local_rank}"
     cdev = dev if args.backend == "nccl" else "cpu"        # where the collectives' tensors live
 
-    strong = world > 1 and args.scaling == "strong"
+    strong = dist_on and args.scaling == "strong"
     total_frames = args.frames or (10000 if strong else 2000)
     cfg = synth.CONFIGS[args.workload]
     ns = max(1, args.streams)
@@ -126,7 +132,7 @@ def main():
     emitted = sum(c[1] for c in calls)
     loaded = sum(c[2] for c in calls)
 
-    gatherer = sharding.TableGatherer(device=cdev) if world > 1 else None
+    gatherer = sharding.TableGatherer(device=cdev) if dist_on else None
     group_ms = {k: 0.0 for k in GROUP_NAMES}
     stats = dict(rows=0, saved=0, crop_bytes=0, contours=0, gather_s=0.0, calls=0, frames=0)
 
@@ -157,13 +163,14 @@ def main():
         n_gather = max((len(calls) + GATHER_EVERY - 1) // GATHER_EVERY, 1)
     nc_ = len(calls)
     group_end = [((g + 1) * nc_) // n_gather for g in range(n_gather)]      # calls [group_end[g-1], group_end[g]) form message g
-    wires = [np.empty(64 << 20, np.uint8) for _ in range(3)] if world > 1 else []
+    wires = [np.empty(64 << 20, np.uint8) for _ in range(3)] if dist_on else []
     gq = _queue.Queue()
     free_wires = _queue.Queue()
     for w_ in wires:
         free_wires.put(w_)
 
     def gather_main():
+        torch.cuda.set_device(local_rank)                    # a new thread starts on device 0
         while True:
             it = gq.get()
             if it is None:
@@ -175,7 +182,7 @@ def main():
                 stats["gather_s"] += time.perf_counter() - g0_
             free_wires.put(buf)
     gth = None
-    if world > 1:
+    if dist_on:
         gth = _threading.Thread(target=gather_main, daemon=True)
         gth.start()
 
@@ -184,7 +191,7 @@ def main():
             self.fill, self.g, self.buf = 0, 0, None
 
         def add(self, c, tab, last, timed):
-            if world == 1:
+            if not dist_on:
                 return
             if self.buf is None:
                 self.buf = free_wires.get()
@@ -197,13 +204,13 @@ def main():
                     self.buf = free_wires.get()
 
         def finish(self, timed):
-            while world > 1 and self.g < n_gather:                           # a rank without parts still takes part in every gather
+            while dist_on and self.g < n_gather:                           # a rank without parts still takes part in every gather
                 gq.put((self.buf if self.buf is not None else free_wires.get(), self.fill, timed))
                 self.g += 1
                 self.fill, self.buf = 0, None
 
     def gathers_done():
-        if world > 1:
+        if dist_on:
             while free_wires.qsize() < len(wires):                           # every message sent and its buffer returned
                 time.sleep(0.0002)
 
@@ -270,17 +277,17 @@ def main():
 
     run_passes(args.warmup, False)
     gathers_done()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     run_passes(args.steps, True)
     gathers_done()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -363,13 +370,13 @@ def main():
                  "frac_of_hbm_peak_per_gpu": round(fps / world * path_bytes / (HBM_PEAK_GBS * 1e9), 4),
                  "frac_of_hbm_peak_per_gpu_with_objects": round(fps / world * (path_bytes + obj_bytes) / (HBM_PEAK_GBS * 1e9), 4),
                  "contexts": ns, "driver": args.driver, "results_checked_after_timed_region": checked,
-                 "ranks_seen": dist.get_world_size() if world > 1 else 1,
+                 "ranks_seen": dist.get_world_size() if dist_on else 1,
                  "halo_overhead": round(halo, 4) if strong else 0.0,
-                 "table_gather_messages_per_step": n_gather if world > 1 else None,
-                 "table_gather_ms_per_step_rank0": round(stats["gather_s"] / max(args.steps, 1) * 1e3, 3) if world > 1 else None},
+                 "table_gather_messages_per_step": n_gather if dist_on else None,
+                 "table_gather_ms_per_step_rank0": round(stats["gather_s"] / max(args.steps, 1) * 1e3, 3) if dist_on else None},
     }
 
-    if rank == 0 and world == 1 and args.host_batches > 0:
+    if rank == 0 and not dist_on and args.host_batches > 0:
         # the same path with the frames starting in (page-locked) host memory and the table + crops ending there: PCIe-bound,
         # reported beside `value`, never as it
         nbh = args.host_batches
@@ -392,7 +399,7 @@ def main():
         finally:
             pipe.close()
 
-    if rank == 0 and world == 1 and args.cpu != "off" and args.cpu_frames >= 12:
+    if rank == 0 and not dist_on and args.cpu != "off" and args.cpu_frames >= 12:
         # the oracle is the timed CPU port here, never the product path.  BASELINE.json configs[0]: 100 frames, seed 1
         nf = args.cpu_frames
         objs, off = synth.make_objects(nf, H, W, 1, **synth.CONFIGS["pisco"])
@@ -426,7 +433,7 @@ def main():
         out["cpu_baseline"] = {"value": round(nf / ct, 3), "unit": "frames/s", "cores": cores, "kind": "port",
                                "sample": f"configs[0]: {nf} frames, seed 1, one batch (window 12), NumPy + C oracle, {how}, "
                                          f"no PNG/CSV writes, host has {os.cpu_count()} logical CPUs", **extra}
-    if world > 1:
+    if dist_on:
         gq.put(None)
         gth.join()
         dist.barrier()
@@ -437,7 +444,7 @@ def main():
     os.dup2(2, 1)
     for sg in segs:
         sg.close()
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 
