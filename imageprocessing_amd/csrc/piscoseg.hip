@@ -93,6 +93,7 @@ struct pseg_ctx {
     int n_saved = 0;
     // host views of the last table (page-locked tail buffer): rows [10][t_hr], saved_row, crop_off
     const int32_t *t_rows = nullptr, *t_saved_row = nullptr; const int64_t *t_crop_off = nullptr; size_t t_hr = 1;
+    int band_cap = 1024, band_calm = 0;   // LDS size class of k_runs_band (BAND_CAP / BAND_CAP_DENSE) and calls since it was needed
     int spec_hold = 0;            // calls for which the fast path stays off (after a batch too dense for the LDS labelling)
     size_t runcap = 0;            // runs the tables are sized for: the labelling chain is queued against it without a host round trip
     struct AsyncWorker *worker = nullptr;   // pseg_submit / pseg_wait: the context's own host thread (started on first use)
@@ -728,11 +729,11 @@ __device__ __forceinline__ bool chain_ok(const SegState &S, uint32_t cap, uint32
 // unions across the band boundaries only: block = the first row of a band (y = BAND_H, 2 BAND_H, ...) of one frame, a
 // thread per run (its foreground unions with the row above, and the gap on its left) plus one for the trailing gap.  The
 // per-element launch (k_unions over all runs and gaps) has one thread in BAND_H with work.
-__global__ __launch_bounds__(64) void k_unions_rows(SegState S, int bandh, uint32_t cap, const uint32_t *__restrict__ bandmax)
+__global__ __launch_bounds__(64) void k_unions_rows(SegState S, int bandh, uint32_t cap, uint32_t bcap)
 {
     // (queued behind k_runs_band before the host has seen the totals: nothing to do when the runs did not fit the tables
     // or a band was too large for the LDS labelling -- the host then takes another path)
-    if (cap == 0 || !chain_ok(S, cap, BAND_CAP)) return;
+    if (cap == 0 || !chain_ok(S, cap, bcap)) return;
     const int f = blockIdx.y, y = ((int)blockIdx.x + 1) * bandh;
     if (y >= S.H) return;
     const int rs = seg_rowstart(S, f, y), n = seg_rowcount(S, f, y);
@@ -854,13 +855,16 @@ __global__ __launch_bounds__(256) void k_band_label(SegState S)
 #define SCAN_AGG (1ull << 62)
 #define SCAN_INC (2ull << 62)
 #define SCAN_SPIN_MAX (1 << 22)
-template <int WPL>
+// CAP = runs a band may hold for the LDS labelling: 1024 (15 KB of LDS, 7 blocks per CU) for ordinary frames, BAND_CAP_DENSE
+// (57 KB, 2 blocks per CU) for dense ones -- the host moves to the larger class when a batch's largest band asks for it
+#define BAND_CAP_DENSE 4096
+template <int WPL, int CAP>
 __global__ __launch_bounds__(256) void k_runs_band(SegState S, int wpl, uint32_t cap, unsigned long long *__restrict__ scan,
                                                    uint32_t *__restrict__ bandmax)
 {
-    __shared__ uint32_t lx[BAND_CAP];                     // run_x of the band's runs
-    __shared__ uint16_t ly[BAND_CAP];                     // band-local row of every run
-    __shared__ int fgp[BAND_CAP], bgp[BAND_CAP + BAND_H];
+    __shared__ uint32_t lx[CAP];                          // run_x of the band's runs
+    __shared__ uint16_t ly[CAP];                          // band-local row of every run
+    __shared__ int fgp[CAP], bgp[CAP + BAND_H];
     __shared__ int lrow[BAND_H + 1];                      // local index of the first run of every row
     __shared__ uint32_t wtot[4];
     __shared__ uint32_t s_ticket, s_base;
@@ -903,7 +907,7 @@ __global__ __launch_bounds__(256) void k_runs_band(SegState S, int wpl, uint32_t
     }
     const uint32_t li = wbase + incl - cnt;               // band-local index of the lane's first run
     if (part == 0) lrow[yl] = (int)li;
-    const bool fits = nb <= BAND_CAP;
+    const bool fits = nb <= CAP;
     // the lane's runs: into LDS when the band fits, else straight to memory once the base is known
     auto emit_runs = [&](auto &&put) {
         uint64_t prev = before;
@@ -2350,9 +2354,12 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
         return 0;
     };
     auto launch_fused = [&](uint32_t capv) {
-        if (runs_wpl > 10) hipLaunchKernelGGL((k_runs_band<16>), dim3(nbpf * n), dim3(256), 0, ctx->cur, S, runs_wpl, capv, scan, bandmax_d);
-        else hipLaunchKernelGGL((k_runs_band<10>), dim3(nbpf * n), dim3(256), 0, ctx->cur, S, runs_wpl, capv, scan, bandmax_d);
-        if (H > BAND_H) hipLaunchKernelGGL(k_unions_rows, dim3((H - 1) / BAND_H, n), dim3(64), 0, ctx->cur, S, BAND_H, capv, (const uint32_t *)bandmax_d);
+        const bool dense = ctx->band_cap > BAND_CAP;
+        if (runs_wpl > 10 && dense) hipLaunchKernelGGL((k_runs_band<16, BAND_CAP_DENSE>), dim3(nbpf * n), dim3(256), 0, ctx->cur, S, runs_wpl, capv, scan, bandmax_d);
+        else if (runs_wpl > 10) hipLaunchKernelGGL((k_runs_band<16, BAND_CAP>), dim3(nbpf * n), dim3(256), 0, ctx->cur, S, runs_wpl, capv, scan, bandmax_d);
+        else if (dense) hipLaunchKernelGGL((k_runs_band<10, BAND_CAP_DENSE>), dim3(nbpf * n), dim3(256), 0, ctx->cur, S, runs_wpl, capv, scan, bandmax_d);
+        else hipLaunchKernelGGL((k_runs_band<10, BAND_CAP>), dim3(nbpf * n), dim3(256), 0, ctx->cur, S, runs_wpl, capv, scan, bandmax_d);
+        if (H > BAND_H) hipLaunchKernelGGL(k_unions_rows, dim3((H - 1) / BAND_H, n), dim3(64), 0, ctx->cur, S, BAND_H, capv, (uint32_t)ctx->band_cap);
     };
     // from the flattening to the size scans; gridded for `runs` runs, guarded by (cap, bcap) on the device
     auto launch_chain = [&](size_t runs, uint32_t capv, uint32_t bcap) {
@@ -2382,11 +2389,12 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
     if (ctx->spec_hold > 0) ctx->spec_hold--;
     bool turn_released = false;
     int nfg = 0;
+    uint32_t band_seen = 0;
     for (;;) {
         if (spec) {
             { int r_ = ensure_tables(ctx->runcap); if (r_) return r_; }
             launch_fused((uint32_t)ctx->runcap);
-            launch_chain(ctx->runcap, (uint32_t)ctx->runcap, BAND_CAP);
+            launch_chain(ctx->runcap, (uint32_t)ctx->runcap, (uint32_t)ctx->band_cap);
         } else {
             { int r_ = ensure_tables(ctx->runcap > 0 ? ctx->runcap : 1); if (r_) return r_; }
             const uint32_t cap0 = fused && ctx->runcap > 0 ? (uint32_t)ctx->runcap : 0u;
@@ -2410,7 +2418,9 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
             const bool fits = fused && cap0 > 0 && nfg_u <= cap0;
             if ((size_t)nfg > ctx->runcap || ctx->runcap == 0) ctx->runcap = (size_t)nfg + (size_t)nfg / 4 + 1024;
             { int r_ = ensure_tables(ctx->runcap); if (r_) return r_; }
-            const bool bands_ok = bandmax <= BAND_CAP && !ctx->no_bands;
+            // (the two-pass path labels with k_band_label, whose tables are the small class)
+            const bool bands_ok = bandmax <= (uint32_t)(fused ? ctx->band_cap : BAND_CAP) && !ctx->no_bands;
+            band_seen = bandmax;
             if (fused && !fits) {                            // the tables were too small: once more
                 HIPCHK(hipMemsetAsync(scan, 0, (size_t)scan_words(ctx, n) * 8, ctx->cur));
                 launch_fused(0xffffffffu);
@@ -2420,7 +2430,7 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
                 if (bands_ok) {
                     // bands of BAND_H rows are labelled in LDS; the global kernels only unite across the band boundaries
                     hipLaunchKernelGGL(k_band_label, dim3(nbpf, n), dim3(256), 0, ctx->cur, S);
-                    if (H > BAND_H) hipLaunchKernelGGL(k_unions_rows, dim3((H - 1) / BAND_H, n), dim3(64), 0, ctx->cur, S, BAND_H, 0xffffffffu, (const uint32_t *)bandmax_d);
+                    if (H > BAND_H) hipLaunchKernelGGL(k_unions_rows, dim3((H - 1) / BAND_H, n), dim3(64), 0, ctx->cur, S, BAND_H, 0xffffffffu, 0xffffffffu);
                 }
             }
             if (!bands_ok) {                                 // frames too dense for the LDS tables (or PSEG_NO_BANDS): global union-find
@@ -2438,7 +2448,7 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
         // instead of 0.93 ms when it shares the CUs, a net loss)
         if (labels) {
             hipLaunchKernelGGL(k_label_fill, dim3((W + 1023) / 1024, H, n), dim3(256), 0, ctx->cur, S,
-                               (const int32_t *)ctx->runlabel.p, labels, spec ? (uint32_t)ctx->runcap : 0xffffffffu, spec ? (uint32_t)BAND_CAP : 0xffffffffu);
+                               (const int32_t *)ctx->runlabel.p, labels, spec ? (uint32_t)ctx->runcap : 0xffffffffu, spec ? (uint32_t)ctx->band_cap : 0xffffffffu);
             HIPCHK(hipGetLastError());
         }
         HIPCHK(hipEventRecord(ctx->ev[4], ctx->cur));
@@ -2451,12 +2461,18 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
         if (h0.totals[6] != 0) return fail(ctx, PSEG_ERR_HIP, "k_runs_band: a block waited for its predecessors' totals for too long");
         if ((unsigned long long)h0.totals[4] > 0x3fffffffull) return fail(ctx, PSEG_ERR_CAPACITY, "too many foreground runs");
         nfg = (int)h0.totals[4];
-        if ((size_t)nfg <= ctx->runcap && h0.totals[5] <= BAND_CAP) break;       // the chain ran
+        band_seen = (uint32_t)h0.totals[5];
+        if ((size_t)nfg <= ctx->runcap && h0.totals[5] <= ctx->band_cap) break;   // the chain ran
         // it did not: more runs than the tables hold, or a band beyond the LDS labelling -- repeat, totals first
-        if (h0.totals[5] > BAND_CAP) ctx->spec_hold = 16;    // dense frames come in stretches: straight to the slow path for a while
+        if (h0.totals[5] > BAND_CAP_DENSE) ctx->spec_hold = 16;   // frames beyond even the large tables come in stretches: straight
+                                                                  // to the slow path (global union-find) for a while
         spec = false;
         HIPCHK(hipMemsetAsync(scan, 0, (size_t)scan_words(ctx, n) * 8, ctx->cur));
     }
+    // size class of the band kernel for the next call: the large tables as soon as a band asked for them, the small ones
+    // again after 8 calls that would have fitted with room to spare
+    if (band_seen > BAND_CAP) { ctx->band_cap = BAND_CAP_DENSE; ctx->band_calm = 0; }
+    else if (ctx->band_cap > BAND_CAP && band_seen <= BAND_CAP * 3 / 4 && ++ctx->band_calm >= 8) { ctx->band_cap = BAND_CAP; ctx->band_calm = 0; }
     ctx->head_on_host = true;
     const HeadHost hh = head_host(ctx, n);
     const uint32_t *h_ftot3 = hh.ftot3, *h_rowbase = hh.rowbase, *h_savedbase = hh.savedbase;
