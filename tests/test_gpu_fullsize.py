@@ -45,6 +45,80 @@ def test_batch_properties(full):
     helpers.check_batch_properties(tab, labels, full["cleaned"], full["mask"])
 
 
+def test_classifier_tensors_of_full_size_crops(full):
+    """BASELINE.json configs[4] at full size, classifier side: the packed device crops of the 30-frame batch go to
+    pseg_vit_tensors without leaving the GPU; a sample of them against PIL's resize of the fetched crops, bit for bit."""
+    from tests.test_gpu_dropin import _pil_classifier_input
+    seg, tab = full["seg"], full["tab"]
+    ns = len(tab.saved_row)
+    assert ns > 400
+    out, valid = seg.vit_tensors(plane="masked")
+    assert out.shape == (ns, 3, 224, 224) and out.is_cuda
+    rng = np.random.default_rng(1)
+    pick = sorted(set(rng.choice(ns, 40, replace=False).tolist()) | {0, ns - 1})
+    got = out[pick].cpu().numpy()
+    for k, s in enumerate(pick):
+        want = _pil_classifier_input(tab.crop(s, "masked"))
+        assert want is not None and valid[s] == 1
+        assert np.array_equal(got[k], want), (s, tab.crop(s, "masked").shape)
+
+
+def test_deconvolution_bridge_at_full_size():
+    """BASELINE.json configs[4] at full size, deconvolution side: background correction -> network on float tensors ->
+    detection on the network's output, everything resident on the GPU (deconvolution.py:70-100 between the two stages).
+    A stand-in network (3 x 3 blur + contrast stretch as elementwise tensor operations; LUCYD's weights cannot be loaded here) runs on the GPU in both
+    cases; two frames against the oracle with the same network applied on the host side of the comparison."""
+    import torch
+    from imageprocessing_amd import deconv_bridge, synth
+    from imageprocessing_amd.engine import Segmenter
+    from oracle import pipeline_ref as ref
+    n = 14
+    seg = Segmenter(H, W, max_frames=n, device=0)
+    try:
+        objs, off = synth.make_objects(n, H, W, 11, **synth.CONFIGS["pisco"])
+        frames = seg.synth_frames(n, 11, objs, off)
+        frames[4] = 77                                       # corrupt: skips the network
+        mask = seg.disk_mask(1200)
+
+        def model(x):                                        # elementwise in a fixed order: the same bits for any batch size
+            p = torch.nn.functional.pad(x, (1, 1, 1, 1))
+            y = 0.4 * x
+            for dy, dx, wgt in ((-1, 0, 0.1), (1, 0, 0.1), (0, -1, 0.1), (0, 1, 0.1), (-1, -1, 0.05), (-1, 1, 0.05), (1, -1, 0.05), (1, 1, 0.05)):
+                y = y + wgt * p[..., 1 + dy:1 + dy + H, 1 + dx:1 + dx + W]
+            return (torch.clamp(1.25 * y - 0.2, 0.0, 1.0), None, None)
+
+        labels = torch.empty((n, H, W), dtype=torch.int32, device="cuda")
+        cleaned, deconv, ms, valid, tab = deconv_bridge.process_with_deconvolution(
+            seg, frames, model, mask=mask, labels=labels, fetch_crops=True)
+        assert valid[4] == 0 and valid.sum() == n - 1 and tab.saved.sum() > 200
+        stack = frames.cpu().numpy()
+        images = [(stack[i], f"img_{i:05d}.png") for i in range(n)]
+        hmask = mask.cpu().numpy()
+        s_of_row = {int(r): s for s, r in enumerate(tab.saved_row)}
+        for i in (2, n - 1):
+            it = ref.correct_img(i, images, 6)
+            assert np.array_equal(cleaned[i].cpu().numpy(), it[1])
+            x_t = torch.from_numpy(it[1] / 255).cuda().unsqueeze(0).unsqueeze(0)
+            d8 = (model(x_t.float())[0].detach().cpu().numpy()[0, 0] * 255).astype(np.uint8)
+            assert np.array_equal(deconv[i].cpu().numpy(), d8)
+            d = ref.detect_on_img((it[0].copy(), d8, it[2], it[3]), hmask, want_labels=True)
+            assert np.array_equal(labels[i].cpu().numpy(), d["labels"])
+            a, b = tab.frame_row_offset[i], tab.frame_row_offset[i + 1]
+            assert b - a == len(d["rows"]) and b - a > 20
+            crops = {c[0]: c for c in d["crops"]}
+            for k, row in enumerate(d["rows"]):
+                assert tab.area[a + k] == row[6] and tab.saved[a + k] == row[11]
+                if row[11]:
+                    assert (tab.x[a + k], tab.y[a + k], tab.w[a + k], tab.h[a + k]) == tuple(row[7:11])
+                    np.testing.assert_allclose(tab.props[a + k], np.array([float(v) for v in row[12:]]), rtol=1e-5, atol=1e-7)
+                    s = s_of_row[a + k]
+                    _, masked, raw, cmask = crops[k]
+                    assert np.array_equal(tab.crop(s, "mask"), cmask) and np.array_equal(tab.crop(s, "masked"), masked)
+                    assert np.array_equal(tab.crop(s, "raw"), raw)
+    finally:
+        seg.close()
+
+
 def test_shared_strips_of_the_last_round_change_nothing(monkeypatch):
     """At this size the background kernel has more blocks than the device holds; the strips of its last, partly filled
     round are walked by several blocks in shorter time ranges.  Same results as with one block per strip."""

@@ -179,7 +179,7 @@ def test_detect_edge_cases(gpu_seg_factory):
 @pytest.mark.parametrize("n,slots", [(61, 0), (130, 5)])
 def test_frame_range_parts_equal_whole_batch(gpu_seg_factory, monkeypatch, n, slots):
     """A batch cut into frame ranges (pseg_process_part with forward halos) gives byte-identical
-    cleaned frames, label maps and merged tables to the batch processed whole.  slots: the background kernel's 12 strips
+    cleaned frames, label maps and merged tables to the batch processed whole, and the whole batch equals the oracle.  slots: the background kernel's 12 strips
     on 5 pretended block slots, so that whole batch and parts share the strips of the last round between two blocks."""
     import torch
     from imageprocessing_amd import sharding
@@ -197,6 +197,9 @@ def test_frame_range_parts_equal_whole_batch(gpu_seg_factory, monkeypatch, n, sl
     labels = torch.empty((n, H, W), dtype=torch.int32, device="cuda")
     cleaned, ms, valid, whole = seg.process(dev, mask=mask, labels=labels, min_area_to_save=100.0)
     ref = sharding.merge_tables([sharding.unpack_table(sharding.pack_table(whole))])
+    # the whole batch against the oracle first, so that "parts == whole" below is anchored and not a self-comparison
+    dets = helpers.oracle_detect(helpers.oracle_bgcorrect(stack), mask.cpu().numpy(), min_area_to_save=100)
+    helpers.compare_table(whole, dets, H, W, labels=labels.cpu().numpy())
     for world in (2, 3, 5):
         blobs = []
         for parts in sharding.plan_ranges(n, world):
