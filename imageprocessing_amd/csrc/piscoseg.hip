@@ -87,6 +87,9 @@ struct pseg_ctx {
     int bounds_tailk = -1;
     bool force_generic = false;   // PSEG_BG_GENERIC=1: use the 12x-read reference kernel (debug / cross-check)
     bool no_bands = false;        // PSEG_NO_BANDS=1: label with the global union-find only (the path of very dense frames)
+    int fill_rows = -1;           // PSEG_FILL_ROWS: 1 = label fill with one wave per row (k_label_fill_rows), 0 = one wave per
+                                  // 256-pixel span, -1 (default) = by the density of the previous batch
+    bool dense_rows = false;      // the last batch had FILL_ROWS_MIN or more runs per row on average
     // host results
     HostBuf h_frame_row_offset, h_frame_n_contours, h_frame_valid, h_frame_mean, h_frame_std, h_area, h_saved8, h_props;
     int64_t crop_bytes = 0;
@@ -135,6 +138,7 @@ static int ensure_pin(pseg_ctx *ctx, PinBuf &b, size_t bytes)
 }
 #define ENSURE_PIN(buf, bytes) do { int r_ = ensure_pin(ctx, (buf), (bytes)); if (r_) return r_; } while (0)
 
+static inline size_t sz_stride(size_t cap) { return (cap + 8 + 1) & ~(size_t)1; }   // a size column of k_emit / k_scan_sizes: even, 8 entries of slack
 static inline int scan_words(const pseg_ctx *ctx, int n) { return 2 + n * ((ctx->H + 63) / 64); }   // (64 = BAND_H)
 
 // head arena for a batch of n frames (u32 words unless noted):
@@ -1243,10 +1247,34 @@ __global__ __launch_bounds__(1024) void k_rank(SegState S, double min_seg, doubl
     if (threadIdx.x < 3) ftot3[f * 3 + threadIdx.x] = carry[threadIdx.x];
 }
 
+#ifndef CROP_BAND
+#define CROP_BAND 32768                // (8192 / 16384 / 65536 px: 1.93 / 1.91 / 1.92 ms per step against 1.90 ms)
+#endif
+#ifndef CROP_THREADS
+#define CROP_THREADS 256
+#endif
+#ifndef CROP_UNROLL
+#define CROP_UNROLL 4
+#endif
+#ifndef CROP_TPR
+#define CROP_TPR 4                   // threads that share the runs of one row while the mask is painted (64 rows at a time;
+                                     // 16 / 8 / 2 threads per row: 0.384 / 0.351 / 0.338 ms for the crop group against 0.334 ms)
+#endif
+#ifndef CROP_LDS_WORDS
+#define CROP_LDS_WORDS 2048          // mask words of a band + 2 halo rows on each side (frames up to 8192 px wide: 8 rows of 256 words)
+#endif
+__host__ __device__ inline int crop_rows_per_band(int w)
+{
+    int r = CROP_BAND / w;
+    // (the band-local 32-bit sums of k_crops_sums: sum yl^2 over a full band < w r^3 / 3 < 2^32 for every w with r <= 600,
+    // and r = CROP_BAND / w <= 585 where w >= 56)
+    if (r > 600) r = 600;
+    return r < 1 ? 1 : r;
+}
 // one row per kept object, ordered (frame, c); c counts from the LAST external root (detection.py:222)
 __global__ void k_emit(SegState S, uint32_t cap, uint32_t bcap, double min_seg, double min_save, const uint32_t *ftot3,
                        const uint32_t *rowbase, const uint32_t *savedbase, RowsDev R, int32_t *objlabel, int32_t *objflag,
-                       int32_t *saved_row, int32_t *runlabel)
+                       int32_t *saved_row, int32_t *runlabel, int32_t *geo, unsigned long long *sz, size_t szstride)
 {
     if (!chain_ok(S, cap, bcap)) return;
     const int nfg = (int)S.framebase[S.F];
@@ -1271,11 +1299,24 @@ __global__ void k_emit(SegState S, uint32_t cap, uint32_t bcap, double min_seg, 
     int i = (int)rowbase[f] + c;
     R.frame[i] = f; R.c[i] = c; R.label[i] = label; R.area2[i] = S.area2[r];
     const int y0 = (int)(S.run_fy[r] & 0xffffu);           // the root run lies in the object's first row
-    R.x[i] = S.minx[r]; R.y[i] = y0;
-    R.w[i] = S.maxx[r] - S.minx[r] + 1; R.h[i] = S.maxy[r] - y0 + 1;
+    const int x = S.minx[r], w = S.maxx[r] - x + 1, h = S.maxy[r] - y0 + 1;
+    R.x[i] = x; R.y[i] = y0;
+    R.w[i] = w; R.h[i] = h;
     R.saved[i] = saved; R.root[i] = r;
     objflag[r] = 1 | (saved ? 2 : 0);
-    if (saved) saved_row[(int)savedbase[f] + (nsaved - 1 - S.savedrank[r])] = i;
+    if (saved) {
+        // geometry of saved object s: geo[s*8] = f, x, y, w, h, root, words-per-row, row; the three size columns
+        // sz[k * szstride + s] = crop bytes | rows (offset of the per-row extremes) | row bands (a band = a run of rows of
+        // about CROP_BAND pixels: the unit of work of k_crops_sums), scanned by k_scan_sizes
+        const size_t sidx = (size_t)savedbase[f] + (size_t)(nsaved - 1 - S.savedrank[r]);
+        saved_row[sidx] = i;
+        int32_t *o = geo + 8 * sidx;
+        o[0] = f; o[1] = x; o[2] = y0; o[3] = w; o[4] = h; o[5] = r; o[6] = (w + 31) >> 5; o[7] = i;
+        const int rpb = crop_rows_per_band(w);
+        sz[sidx] = (unsigned long long)w * h;
+        sz[szstride + sidx] = (unsigned long long)h;
+        sz[2 * szstride + sidx] = (unsigned long long)((h + rpb - 1) / rpb);
+    }
 }
 
 // label map: one dense pass writes every int32 exactly once.  Wave = one 256-pixel span of a row
@@ -1284,6 +1325,7 @@ __global__ void k_emit(SegState S, uint32_t cap, uint32_t bcap, double min_seg, 
 // Otherwise the wave works together: the row's runs and their labels are loaded one per lane, the runs that meet the
 // span are broadcast one after the other (typically one or two) and every lane takes what falls on its pixels.
 typedef int32_t i32x4_t __attribute__((ext_vector_type(4)));
+#define FILL_ROWS_MIN 8
 // grid = (ceil(W / 1024), H, frames): row and frame come from the block index (no divisions; at one KiB per wave the
 // kernel only streams at full rate while a wave spends a few dozen instructions)
 __global__ __launch_bounds__(256) void k_label_fill(SegState S, const int32_t *__restrict__ runlabel, int32_t *__restrict__ labels,
@@ -1321,51 +1363,62 @@ __global__ __launch_bounds__(256) void k_label_fill(SegState S, const int32_t *_
     if (in) __builtin_nontemporal_store(out, (i32x4_t *)(labels + rowpix + x));
 }
 
-// geometry of saved object s: geo[s*8] = f, x, y, w, h, root, words-per-row, row ; sz[s*3] = crop bytes,
-// mask words, row bands (a band = a run of rows of about CROP_BAND pixels: the unit of work of k_crops_sums)
-#ifndef CROP_BAND
-#define CROP_BAND 32768                // (8192 / 16384 / 65536 px: 1.93 / 1.91 / 1.92 ms per step against 1.90 ms)
-#endif
-#ifndef CROP_THREADS
-#define CROP_THREADS 256
-#endif
-#ifndef CROP_UNROLL
-#define CROP_UNROLL 4
-#endif
-#ifndef CROP_TPR
-#define CROP_TPR 4                   // threads that share the runs of one row while the mask is painted (64 rows at a time;
-                                     // 16 / 8 / 2 threads per row: 0.384 / 0.351 / 0.338 ms for the crop group against 0.334 ms)
-#endif
-#ifndef CROP_LDS_WORDS
-#define CROP_LDS_WORDS 2048          // mask words of a band + 2 halo rows on each side (frames up to 8192 px wide: 8 rows of 256 words)
-#endif
-__host__ __device__ inline int crop_rows_per_band(int w)
-{
-    int r = CROP_BAND / w;
-    // (the band-local 32-bit sums of k_crops_sums: sum yl^2 over a full band < w r^3 / 3 < 2^32 for every w with r <= 600,
-    // and r = CROP_BAND / w <= 585 where w >= 56)
-    if (r > 600) r = 600;
-    return r < 1 ? 1 : r;
-}
-__global__ void k_saved_geo(SegState S, uint32_t cap, uint32_t bcap, const uint32_t *n_saved_p, const int32_t *saved_row, RowsDev R,
-                            int32_t *geo, unsigned long long *sz)
+// The same map with one wave per ROW (block = 4 consecutive rows): the row's first 64 runs and their labels are loaded
+// once and kept in registers while the wave walks the row's 256-pixel spans, so that a wave's two dependent table loads
+// are paid once per row (10 KiB at W = 2560) instead of once per KiB.  For rows with many runs (dense frames).
+__global__ __launch_bounds__(256) void k_label_fill_rows(SegState S, const int32_t *__restrict__ runlabel, int32_t *__restrict__ labels,
+                                                         uint32_t cap, uint32_t bcap)
 {
     if (!chain_ok(S, cap, bcap)) return;
-    size_t g = GTID;
-    if (g >= (size_t)*n_saved_p) return;
-    int i = saved_row[g];
-    int w = R.w[i], h = R.h[i], wpr = (w + 31) >> 5;
-    int32_t *o = geo + 8 * g;
-    o[0] = R.frame[i]; o[1] = R.x[i]; o[2] = R.y[i]; o[3] = w; o[4] = h; o[5] = R.root[i]; o[6] = wpr; o[7] = i;
-    int rpb = crop_rows_per_band(w);
-    sz[3 * g] = (unsigned long long)w * h;
-    sz[3 * g + 1] = (unsigned long long)h;                 // rows: offset of the object's per-row extremes
-    sz[3 * g + 2] = (unsigned long long)((h + rpb - 1) / rpb);
+    const int lane = threadIdx.x & 63;
+    const int f = blockIdx.z, y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (y >= S.H) return;
+    const size_t rowpix = ((size_t)f * S.H + y) * S.W;
+    const int rs = seg_rowstart(S, f, y), n = seg_rowcount(S, f, y);
+    uint32_t rx0 = 0xffffu; int lab0 = 0;                    // lanes past the row's runs: xs = 65535, xe = 0
+    if (lane < n) { rx0 = S.run_x[rs + lane]; lab0 = runlabel[rs + lane]; }
+    const int xs0 = (int)(rx0 & 0xffffu), xe0 = (int)(rx0 >> 16);
+    for (int x0 = 0; x0 < S.W; x0 += 256) {
+        const int x = x0 + 4 * lane;
+        i32x4_t out = {0, 0, 0, 0};
+        unsigned long long hit = __ballot(lab0 != 0 && xe0 >= x0 && xs0 <= x0 + 255);
+        while (hit) {
+            const int l = __builtin_ctzll(hit);
+            hit &= hit - 1;
+            const int a = __builtin_amdgcn_readlane(xs0, l), b = __builtin_amdgcn_readlane(xe0, l), lb = __builtin_amdgcn_readlane(lab0, l);
+            if (a <= x && x <= b) out.x = lb;
+            if (a <= x + 1 && x + 1 <= b) out.y = lb;
+            if (a <= x + 2 && x + 2 <= b) out.z = lb;
+            if (a <= x + 3 && x + 3 <= b) out.w = lb;
+        }
+        if (n > 64 && __builtin_amdgcn_readlane(xs0, 63) <= x0 + 255) {       // (runs are sorted) the later batches, from memory
+            for (int j0 = 64; j0 < n; j0 += 64) {
+                uint32_t rx = 0xffffu; int lab = 0;
+                if (j0 + lane < n) { rx = S.run_x[rs + j0 + lane]; lab = runlabel[rs + j0 + lane]; }
+                const int xs = (int)(rx & 0xffffu), xe = (int)(rx >> 16);
+                hit = __ballot(lab != 0 && xe >= x0 && xs <= x0 + 255);
+                while (hit) {
+                    const int l = __builtin_ctzll(hit);
+                    hit &= hit - 1;
+                    const int a = __builtin_amdgcn_readlane(xs, l), b = __builtin_amdgcn_readlane(xe, l), lb = __builtin_amdgcn_readlane(lab, l);
+                    if (a <= x && x <= b) out.x = lb;
+                    if (a <= x + 1 && x + 1 <= b) out.y = lb;
+                    if (a <= x + 2 && x + 2 <= b) out.z = lb;
+                    if (a <= x + 3 && x + 3 <= b) out.w = lb;
+                }
+                if (__builtin_amdgcn_readlane(xs, 63) > x0 + 255) break;
+            }
+        }
+        if (x < S.W) __builtin_nontemporal_store(out, (i32x4_t *)(labels + rowpix + x));
+    }
 }
+
 // exclusive scans of the three size columns by one block of 1024 threads; out[k][0..n].  A thread takes 8 consecutive
-// objects (one pass of wave / block scans per 8192 objects)
+// objects (one pass of wave / block scans per 8192 objects), read and written as 16-byte vectors: the columns are
+// stored one after the other (stride `szstride`, even, with 8 entries of slack behind each column)
 #define SCAN_IPT 8
-__global__ __launch_bounds__(1024) void k_scan_sizes(SegState S, uint32_t cap, uint32_t bcap, const unsigned long long *sz,
+typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(1024) void k_scan_sizes(SegState S, uint32_t cap, uint32_t bcap, const unsigned long long *sz, size_t szstride,
                                                       const uint32_t *n_p, long long *crop_off, long long *bits_off,
                                                       long long *band_off, long long *totals)
 {
@@ -1381,12 +1434,19 @@ __global__ __launch_bounds__(1024) void k_scan_sizes(SegState S, uint32_t cap, u
     unsigned long long hmax = 0;                             // tallest saved object (LDS size of k_convex): totals[3]
     for (int base = 0; base < n; base += 1024 * SCAN_IPT) {
         const int i0 = base + threadIdx.x * SCAN_IPT;
-        unsigned long long v[SCAN_IPT][3], tot[3] = {0, 0, 0}, inc[3];
+        unsigned long long v[3][SCAN_IPT], tot[3] = {0, 0, 0}, inc[3];
 #pragma unroll
-        for (int j = 0; j < SCAN_IPT; j++) {
-            for (int k = 0; k < 3; k++) { v[j][k] = (i0 + j < n) ? sz[3 * (size_t)(i0 + j) + k] : 0; tot[k] += v[j][k]; }
-            hmax = v[j][1] > hmax ? v[j][1] : hmax;          // column 1 = rows of the object
+        for (int k = 0; k < 3; k++) {
+            if (i0 < n) {
+                const u64x2_t *p = (const u64x2_t *)(sz + k * szstride + i0);
+#pragma unroll
+                for (int q = 0; q < SCAN_IPT / 2; q++) { const u64x2_t t = p[q]; v[k][2 * q] = t.x; v[k][2 * q + 1] = t.y; }
+            }
+#pragma unroll
+            for (int j = 0; j < SCAN_IPT; j++) { if (i0 + j >= n) v[k][j] = 0; tot[k] += v[k][j]; }
         }
+#pragma unroll
+        for (int j = 0; j < SCAN_IPT; j++) hmax = v[1][j] > hmax ? v[1][j] : hmax;   // column 1 = rows of the object
         for (int k = 0; k < 3; k++) {                        // inclusive scan of the thread totals inside the wave
             unsigned long long x = tot[k];
             for (int o = 1; o < 64; o <<= 1) { unsigned long long t = __shfl_up(x, o, 64); if (lane >= o) x += t; }
@@ -1396,10 +1456,20 @@ __global__ __launch_bounds__(1024) void k_scan_sizes(SegState S, uint32_t cap, u
         __syncthreads();
         unsigned long long pre[3] = {carry[0], carry[1], carry[2]};
         for (int w = 0; w < wv; w++) for (int k = 0; k < 3; k++) pre[k] += wtot[w][k];
+#pragma unroll
         for (int k = 0; k < 3; k++) {
             unsigned long long run = pre[k] + inc[k] - tot[k];
+            if (i0 + SCAN_IPT <= n) {
+                u64x2_t *o = (u64x2_t *)(outp[k] + i0);
 #pragma unroll
-            for (int j = 0; j < SCAN_IPT; j++) { if (i0 + j < n) outp[k][i0 + j] = (long long)run; run += v[j][k]; }
+                for (int q = 0; q < SCAN_IPT / 2; q++) {
+                    u64x2_t t; t.x = run; run += v[k][2 * q]; t.y = run; run += v[k][2 * q + 1];
+                    o[q] = t;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < SCAN_IPT; j++) { if (i0 + j < n) outp[k][i0 + j] = (long long)run; run += v[k][j]; }
+            }
         }
         __syncthreads();
         if (threadIdx.x == 1023) for (int k = 0; k < 3; k++) carry[k] = pre[k] + inc[k];
@@ -1945,6 +2015,7 @@ extern "C" int pseg_create(int device, int H, int W, int max_frames, pseg_ctx **
     if (const char *e = getenv("PSEG_SHARED_STREAM")) ctx->shared_stream = atoi(e) != 0;
     if (const char *e = getenv("PSEG_RUNS_OLD")) ctx->runs_old = atoi(e) != 0;
     if (const char *e = getenv("PSEG_NO_BANDS")) ctx->no_bands = atoi(e) != 0;
+    if (const char *e = getenv("PSEG_FILL_ROWS")) ctx->fill_rows = atoi(e);
     for (auto &e : ctx->ev) if (hipEventCreate(&e) != hipSuccess) { pseg_destroy(ctx); return PSEG_ERR_HIP; }   // frees what exists so far
     *out = ctx;
     return PSEG_OK;
@@ -2335,7 +2406,7 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
         ENSURE(ctx->objlabel, cap * 4); ENSURE(ctx->objflag, cap * 4); ENSURE(ctx->runlabel, cap * 4);
         ENSURE(ctx->rows, cap * 10 * 4);                     // rows: one per kept object; n_rows <= external roots <= runs
         ENSURE(ctx->saved_row, cap * 4);
-        ENSURE(ctx->saved_geo, cap * 8 * 4 + cap * 3 * 8);
+        ENSURE(ctx->saved_geo, cap * 8 * 4 + 3 * sz_stride(cap) * 8);
         ENSURE(ctx->crop_off, (cap + 1) * 8); ENSURE(ctx->bits_off, (cap + 1) * 8); ENSURE(ctx->band_off, (cap + 1) * 8);
         S.run_x = (uint32_t *)ctx->run_x.p; S.run_fy = (uint32_t *)ctx->run_fy.p;
         S.fg_parent = (int32_t *)ctx->fg_parent.p; S.ext = (int32_t *)ctx->ext.p; S.gapl = (int32_t *)ctx->gapl.p;
@@ -2371,14 +2442,11 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
         }
         hipLaunchKernelGGL(k_rank, dim3(n), dim3(1024), 0, ctx->cur, S, min_seg, min_save, ftot3, capv, bcap);
         hipLaunchKernelGGL(k_scan_small, dim3(2), dim3(256), 0, ctx->cur, (const uint32_t *)(ftot3 + 1), rowbase, n, 3, 1);   // rowbase | savedbase
-        if (runs > 0) {
+        if (runs > 0)
             hipLaunchKernelGGL(k_emit, dim3(nblocks(runs)), dim3(256), 0, ctx->cur, S, capv, bcap, min_seg, min_save, (const uint32_t *)ftot3,
                                (const uint32_t *)rowbase, (const uint32_t *)savedbase, R, objlabel, objflag, saved_row,
-                               (int32_t *)ctx->runlabel.p);
-            hipLaunchKernelGGL(k_saved_geo, dim3(nblocks(runs)), dim3(256), 0, ctx->cur, S, capv, bcap, (const uint32_t *)(savedbase + n),
-                               (const int32_t *)saved_row, R, geo, sz);
-        }
-        hipLaunchKernelGGL(k_scan_sizes, dim3(1), dim3(1024), 0, ctx->cur, S, capv, bcap, (const unsigned long long *)sz,
+                               (int32_t *)ctx->runlabel.p, geo, sz, sz_stride(rcap));
+        hipLaunchKernelGGL(k_scan_sizes, dim3(1), dim3(1024), 0, ctx->cur, S, capv, bcap, (const unsigned long long *)sz, sz_stride(rcap),
                            (const uint32_t *)(savedbase + n), (long long *)ctx->crop_off.p, (long long *)ctx->bits_off.p,
                            (long long *)ctx->band_off.p, totals);
     };
@@ -2447,6 +2515,15 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
         // (running the label fill on a second stream next to the crop / property kernels was measured: the fill takes 2.0 ms
         // instead of 0.93 ms when it shares the CUs, a net loss)
         if (labels) {
+            // one wave per row where rows hold many runs (FILL_ROWS_MIN per row on average: 1.0 ms against 1.7 ms at 19 runs per
+            // row), one wave per 256-pixel span otherwise (0.86 ms against 0.96 ms at 3 runs per row); the speculative chain
+            // does not know this batch's count yet and goes by the previous batch
+            const bool by_rows = ctx->fill_rows >= 0 ? ctx->fill_rows > 0
+                                                     : (spec ? ctx->dense_rows : (size_t)nfg >= (size_t)n * H * FILL_ROWS_MIN);
+            if (by_rows)
+                hipLaunchKernelGGL(k_label_fill_rows, dim3(1, (H + 3) / 4, n), dim3(256), 0, ctx->cur, S,
+                                   (const int32_t *)ctx->runlabel.p, labels, spec ? (uint32_t)ctx->runcap : 0xffffffffu, spec ? (uint32_t)ctx->band_cap : 0xffffffffu);
+            else
             hipLaunchKernelGGL(k_label_fill, dim3((W + 1023) / 1024, H, n), dim3(256), 0, ctx->cur, S,
                                (const int32_t *)ctx->runlabel.p, labels, spec ? (uint32_t)ctx->runcap : 0xffffffffu, spec ? (uint32_t)ctx->band_cap : 0xffffffffu);
             HIPCHK(hipGetLastError());
@@ -2471,6 +2548,7 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
     }
     // size class of the band kernel for the next call: the large tables as soon as a band asked for them, the small ones
     // again after 8 calls that would have fitted with room to spare
+    ctx->dense_rows = (size_t)nfg >= (size_t)n * H * FILL_ROWS_MIN;
     if (band_seen > BAND_CAP) { ctx->band_cap = BAND_CAP_DENSE; ctx->band_calm = 0; }
     else if (ctx->band_cap > BAND_CAP && band_seen <= BAND_CAP * 3 / 4 && ++ctx->band_calm >= 8) { ctx->band_cap = BAND_CAP; ctx->band_calm = 0; }
     ctx->head_on_host = true;
