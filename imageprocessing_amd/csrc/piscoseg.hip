@@ -1269,6 +1269,8 @@ __host__ __device__ inline int crop_rows_per_band(int w)
     // (the band-local 32-bit sums of k_crops_sums: sum yl^2 over a full band < w r^3 / 3 < 2^32 for every w with r <= 600,
     // and r = CROP_BAND / w <= 585 where w >= 56)
     if (r > 600) r = 600;
+    const int fit = CROP_LDS_WORDS / ((w + 31) >> 5) - 4;  // rows + 4 halo rows of (w + 31) / 32 words fit the LDS arrays
+    if (r > fit) r = fit;
     return r < 1 ? 1 : r;
 }
 // one row per kept object, ordered (frame, c); c counts from the LAST external root (detection.py:222)
@@ -1486,14 +1488,28 @@ __global__ __launch_bounds__(1024) void k_scan_sizes(SegState S, uint32_t cap, u
     }
 }
 
-// band -> saved object (one wave per object), so that a band's block starts with one load instead of a binary search
-__global__ __launch_bounds__(256) void k_band_map(int n_saved, const long long *__restrict__ band_off, int32_t *__restrict__ band_obj,
-                                                  long long *__restrict__ sums)
+// band -> saved object (one wave per object): every band gets a 64-byte descriptor -- the object's geometry, its index, the
+// band's first row, the object's offsets into the crop planes and the row-extremes table -- so that a band's block starts
+// with ONE (scalar) load instead of the chain band -> object -> geometry / offsets.
+//   desc[0..7] = f, x, y, w, h, root, words per row, object ; [8] = first row ; [10..11] = crop offset ; [12..13] = row offset
+#define BAND_DESC_INTS 16
+__global__ __launch_bounds__(256) void k_band_map(int n_saved, const long long *__restrict__ band_off, const int32_t *__restrict__ geo,
+                                                  const long long *__restrict__ crop_off, const long long *__restrict__ row_off,
+                                                  int32_t *__restrict__ band_desc, long long *__restrict__ sums)
 {
-    const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int s = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (s >= n_saved) return;
-    if ((threadIdx.x & 63) < PSEG_NSUMS) sums[(size_t)s * PSEG_NSUMS + (threadIdx.x & 63)] = (threadIdx.x & 63) == 6 ? 255 : 0;   // min intensity starts at 255
-    for (long long b = band_off[s] + (threadIdx.x & 63); b < band_off[s + 1]; b += 64) band_obj[b] = s;
+    if (lane < PSEG_NSUMS) sums[(size_t)s * PSEG_NSUMS + lane] = lane == 6 ? 255 : 0;   // min intensity starts at 255
+    const int4 g0 = *(const int4 *)(geo + 8 * (size_t)s), g1 = *(const int4 *)(geo + 8 * (size_t)s + 4);
+    const long long b0 = band_off[s], b1 = band_off[s + 1], co = crop_off[s], ro = row_off[s];
+    const int rpb = crop_rows_per_band(g0.w);
+    for (long long b = b0 + lane; b < b1; b += 64) {
+        int4 *d = (int4 *)(band_desc + BAND_DESC_INTS * (size_t)b);
+        d[0] = g0;
+        d[1] = make_int4(g1.x, g1.y, g1.z, s);
+        d[2] = make_int4((int)(b - b0) * rpb, 0, (int)(uint32_t)co, (int)(co >> 32));
+        d[3] = make_int4((int)(uint32_t)ro, (int)(ro >> 32), 0, 0);
+    }
 }
 
 __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
@@ -1525,17 +1541,29 @@ __global__ __launch_bounds__(CROP_THREADS) void k_crops_sums(SegState S, int n_s
                                                     const uint8_t *__restrict__ raw, uint8_t *__restrict__ c_raw,
                                                     uint8_t *__restrict__ c_masked, uint8_t *__restrict__ c_mask, long long *sums,
                                                     const long long *__restrict__ row_off, int32_t *__restrict__ rowext,
-                                                    const int32_t *__restrict__ band_obj, const uint8_t *__restrict__ dense_mask)
+                                                    const int32_t *__restrict__ band_obj, const uint8_t *__restrict__ dense_mask,
+                                                    const int32_t *__restrict__ band_desc)
 {
     __shared__ uint32_t mbuf[CROP_LDS_WORDS];             // mask bits of rows r0-2 .. r1+1 (zero outside the window)
     __shared__ uint32_t bd[CROP_LDS_WORDS];               // 4-neighbour border bits of rows r0-1 .. r1
     __shared__ uint32_t acc[32];                          // block totals (see the end of the kernel)
     const long long bid = blockIdx.x;
-    const int s = band_obj[bid];                          // band_off[s] <= blockIdx.x < band_off[s+1]
-    const int32_t *o = geo + 8 * (size_t)s;
-    const int f = o[0], bx = o[1], by = o[2], w = o[3], h = o[4], root = o[5], wpr = o[6];
+    int s, f, bx, by, w, h, root, wpr, r0;
+    long long coff, roff;
+    if (band_desc) {                                      // (k_band_map's descriptor: block-uniform, one load)
+        const int32_t *d = band_desc + BAND_DESC_INTS * (size_t)bid;
+        f = d[0]; bx = d[1]; by = d[2]; w = d[3]; h = d[4]; root = d[5]; wpr = d[6]; s = d[7]; r0 = d[8];
+        coff = (long long)(((unsigned long long)(uint32_t)d[11] << 32) | (uint32_t)d[10]);
+        roff = (long long)(((unsigned long long)(uint32_t)d[13] << 32) | (uint32_t)d[12]);
+    } else {                                              // pseg_regionprops: band -> object -> geometry
+        s = band_obj[bid];                                // band_off[s] <= blockIdx.x < band_off[s+1]
+        const int32_t *o = geo + 8 * (size_t)s;
+        f = o[0]; bx = o[1]; by = o[2]; w = o[3]; h = o[4]; root = o[5]; wpr = o[6];
+        r0 = (int)(bid - band_off[s]) * crop_rows_per_band(w);
+        coff = crop_off[s]; roff = row_off[s];
+    }
     const int rpb = crop_rows_per_band(w);
-    const int r0 = (int)(bid - band_off[s]) * rpb, r1 = (r0 + rpb < h) ? r0 + rpb : h;
+    const int r1 = (r0 + rpb < h) ? r0 + rpb : h;
     const int nrows = r1 - r0;
     const float rcp_wpr = 1.0f / (float)wpr, rcp_wpr1 = 1.0f / (float)(wpr + 1);
     for (int wi = threadIdx.x; wi < (nrows + 4) * wpr; wi += CROP_THREADS) mbuf[wi] = 0;
@@ -1576,8 +1604,9 @@ __global__ __launch_bounds__(CROP_THREADS) void k_crops_sums(SegState S, int n_s
                 const int xs = (int)(rx & 0xffffu), xe = (int)(rx >> 16);
                 const int pe = j > 0 ? run_xe(S, r - 1) : x_hi;      // j == 0: the leading gap belongs to no object
                 const int idr = S.ext[r], idg = S.gapl[r];
-                if (xe >= x_lo && xs <= x_hi && idr >= root && (objflag[idr] & 2)) paint(mrow, xs, xe);
-                if (xs - 1 >= x_lo && pe + 1 <= x_hi && idg >= root && (objflag[idg] & 2)) paint(mrow, pe + 1, xs - 1);
+                // (the object itself is saved by definition: the flag is only looked up for other objects inside the window)
+                if (xe >= x_lo && xs <= x_hi && (idr == root || (idr > root && (objflag[idr] & 2)))) paint(mrow, xs, xe);
+                if (xs - 1 >= x_lo && pe + 1 <= x_hi && (idg == root || (idg > root && (objflag[idg] & 2)))) paint(mrow, pe + 1, xs - 1);
             }
         }
     }
@@ -1600,7 +1629,7 @@ __global__ __launch_bounds__(CROP_THREADS) void k_crops_sums(SegState S, int n_s
     // block-uniform bases; per-item offsets stay 32-bit
     const uint8_t *sb = cleaned + (size_t)f * P + (size_t)(by + r0) * S.W + bx;
     const uint8_t *rb = raw + (size_t)f * P + (size_t)(by + r0) * S.W + bx;
-    const long long off = crop_off[s] + (long long)r0 * w;
+    const long long off = coff + (long long)r0 * w;
     uint8_t *o_raw = c_raw + off, *o_mask = c_mask + off, *o_masked = c_masked + off;
     uint32_t isum = 0, mn_e = 0x00ff00ffu, mn_o = 0x00ff00ffu, mx_e = 0, mx_o = 0;   // intensities: byte lanes as u16 pairs
     if (w >= 16) {
@@ -1801,8 +1830,8 @@ __global__ __launch_bounds__(CROP_THREADS) void k_crops_sums(SegState S, int n_s
         int first = 0x7fffffff, last = -1;
         for (int wx = 0; wx < wpr; wx++) if (m[wx]) { first = 32 * wx + __ffs(m[wx]) - 1; break; }
         for (int wx = wpr - 1; wx >= 0; wx--) if (m[wx]) { last = 32 * wx + 31 - __clz(m[wx]); break; }
-        rowext[2 * (row_off[s] + r0 + yl)] = first;
-        rowext[2 * (row_off[s] + r0 + yl) + 1] = last;
+        rowext[2 * (roff + r0 + yl)] = first;
+        rowext[2 * (roff + r0 + yl) + 1] = last;
     }
     // block totals: DPP wave sums (every partial fits 32 bits, see above), lane 63 adds them into LDS, one thread flushes
     // with 64-bit integer atomics (exact, order-independent)
@@ -1996,7 +2025,8 @@ extern "C" int pseg_create(int device, int H, int W, int max_frames, pseg_ctx **
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device || device < 0) { delete ctx; return PSEG_ERR_NODEVICE; }
     ctx->device = device; ctx->H = H; ctx->W = W; ctx->WW = W / 64; ctx->maxF = max_frames; ctx->P = (size_t)H * W;
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return PSEG_ERR_HIP; }
+    if (hipSetDevice(device) != hipSuccess) { delete ctx; return PSEG_ERR_HIP; }
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return PSEG_ERR_HIP; }
     // (non-blocking streams: a caller that synchronises the legacy default stream -- torch's current stream, before it hands
     // over its tensors -- must not wait for the batches other contexts have in flight on the library's streams)
     ctx->own_stream = true;
@@ -2450,6 +2480,20 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
                            (const uint32_t *)(savedbase + n), (long long *)ctx->crop_off.p, (long long *)ctx->bits_off.p,
                            (long long *)ctx->band_off.p, totals);
     };
+    auto launch_fill = [&](bool spec_, int nfg_) -> int {
+        // one wave per row where rows hold many runs (FILL_ROWS_MIN per row on average: 1.0 ms against 1.7 ms at 19 runs per
+        // row), one wave per 256-pixel span otherwise (0.86 ms against 0.96 ms at 3 runs per row); the speculative chain
+        // does not know this batch's count yet and goes by the previous batch
+        const bool by_rows = ctx->fill_rows >= 0 ? ctx->fill_rows > 0
+                                                 : (spec_ ? ctx->dense_rows : (size_t)nfg_ >= (size_t)n * H * FILL_ROWS_MIN);
+        const uint32_t c0 = spec_ ? (uint32_t)ctx->runcap : 0xffffffffu, c1 = spec_ ? (uint32_t)ctx->band_cap : 0xffffffffu;
+        if (by_rows)
+            hipLaunchKernelGGL(k_label_fill_rows, dim3(1, (H + 3) / 4, n), dim3(256), 0, ctx->cur, S, (const int32_t *)ctx->runlabel.p, labels, c0, c1);
+        else
+            hipLaunchKernelGGL(k_label_fill, dim3((W + 1023) / 1024, H, n), dim3(256), 0, ctx->cur, S, (const int32_t *)ctx->runlabel.p, labels, c0, c1);
+        HIPCHK(hipGetLastError());
+        return 0;
+    };
     // Fast path: the whole chain is queued at once, sized by the tables' capacity (what the largest batch so far needed plus a
     // quarter); the host looks at the totals only when the head arrives, behind the label fill.  Slow path (first batch, a
     // denser batch, bands beyond the LDS labelling, very wide rows): totals first, then the chain.
@@ -2514,20 +2558,7 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
         HIPCHK(hipEventRecord(ctx->ev[3], ctx->cur));
         // (running the label fill on a second stream next to the crop / property kernels was measured: the fill takes 2.0 ms
         // instead of 0.93 ms when it shares the CUs, a net loss)
-        if (labels) {
-            // one wave per row where rows hold many runs (FILL_ROWS_MIN per row on average: 1.0 ms against 1.7 ms at 19 runs per
-            // row), one wave per 256-pixel span otherwise (0.86 ms against 0.96 ms at 3 runs per row); the speculative chain
-            // does not know this batch's count yet and goes by the previous batch
-            const bool by_rows = ctx->fill_rows >= 0 ? ctx->fill_rows > 0
-                                                     : (spec ? ctx->dense_rows : (size_t)nfg >= (size_t)n * H * FILL_ROWS_MIN);
-            if (by_rows)
-                hipLaunchKernelGGL(k_label_fill_rows, dim3(1, (H + 3) / 4, n), dim3(256), 0, ctx->cur, S,
-                                   (const int32_t *)ctx->runlabel.p, labels, spec ? (uint32_t)ctx->runcap : 0xffffffffu, spec ? (uint32_t)ctx->band_cap : 0xffffffffu);
-            else
-            hipLaunchKernelGGL(k_label_fill, dim3((W + 1023) / 1024, H, n), dim3(256), 0, ctx->cur, S,
-                               (const int32_t *)ctx->runlabel.p, labels, spec ? (uint32_t)ctx->runcap : 0xffffffffu, spec ? (uint32_t)ctx->band_cap : 0xffffffffu);
-            HIPCHK(hipGetLastError());
-        }
+        if (labels) { int r_ = launch_fill(spec, nfg); if (r_) return r_; }
         HIPCHK(hipEventRecord(ctx->ev[4], ctx->cur));
         // The streaming kernels of this batch are queued.  What follows (crops, properties, hulls) waits on memory latency and
         // fills neither the vector units nor the memory system: the next batch's background kernel may run beside it.
@@ -2568,14 +2599,15 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
         if (h_tot[2] > 0x7fffffffLL) return fail(ctx, PSEG_ERR_CAPACITY, "too many crop bands");
         ENSURE(ctx->crops_raw, (size_t)h_tot[0]); ENSURE(ctx->crops_masked, (size_t)h_tot[0]); ENSURE(ctx->crops_mask, (size_t)h_tot[0]);
         ENSURE(ctx->maskbits, (size_t)h_tot[1] * 2 * 4);     // first / last column of every window row (convex hull input)
-        ENSURE(ctx->band_obj, (size_t)h_tot[2] * 4);
+        ENSURE(ctx->band_obj, (size_t)h_tot[2] * BAND_DESC_INTS * 4);
         hipLaunchKernelGGL(k_band_map, dim3(nblocks((size_t)n_saved, 4)), dim3(256), 0, ctx->cur, n_saved, (const long long *)ctx->band_off.p,
+                           (const int32_t *)geo, (const long long *)ctx->crop_off.p, (const long long *)ctx->bits_off.p,
                            (int32_t *)ctx->band_obj.p, d_sums);
         hipLaunchKernelGGL(k_crops_sums<false>, dim3((unsigned)h_tot[2]), dim3(CROP_THREADS), 0, ctx->cur, S, n_saved, (const int32_t *)geo,
                            (const long long *)ctx->crop_off.p, (const long long *)ctx->band_off.p, (const int32_t *)objflag,
                            cleaned, raw, (uint8_t *)ctx->crops_raw.p, (uint8_t *)ctx->crops_masked.p,
                            (uint8_t *)ctx->crops_mask.p, d_sums, (const long long *)ctx->bits_off.p,
-                           (int32_t *)ctx->maskbits.p, (const int32_t *)ctx->band_obj.p, (const uint8_t *)nullptr);
+                           (int32_t *)ctx->maskbits.p, (const int32_t *)nullptr, (const uint8_t *)nullptr, (const int32_t *)ctx->band_obj.p);
         const int hmax = (int)h_tot[3];
         // two size classes when tall objects are present: objects up to 256 rows keep 14 KB of LDS per block, the rest is sized by
         // the tallest one
@@ -2966,7 +2998,7 @@ extern "C" int pseg_regionprops(pseg_ctx *ctx, const uint8_t *mask, const uint8_
     hipLaunchKernelGGL(k_init_sums, dim3(1), dim3(256), 0, st, d_sums, 1);
     hipLaunchKernelGGL(k_crops_sums<true>, dim3(nbands), dim3(CROP_THREADS), 0, st, S, 1, (const int32_t *)(d + o_geo), (const long long *)(d + o_ll),
                        (const long long *)(d + o_ll + 16), (const int32_t *)nullptr, img, img, c0, c0 + (size_t)w * h, c0 + (size_t)2 * w * h,
-                       d_sums, (const long long *)(d + o_ll + 32), (int32_t *)(d + o_ext), (const int32_t *)(d + o_bobj), mask);
+                       d_sums, (const long long *)(d + o_ll + 32), (int32_t *)(d + o_ext), (const int32_t *)(d + o_bobj), mask, (const int32_t *)nullptr);
     if (lds > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void *)k_convex, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_convex, dim3(1), dim3(128), lds, st, 1, (const int32_t *)(d + o_geo), (const long long *)(d + o_ll + 32),
                        (const int32_t *)(d + o_ext), d_sums, 0, h);
@@ -3060,7 +3092,7 @@ extern "C" int pseg_regionprops_noalloc(pseg_ctx *ctx, const uint8_t *mask, cons
     hipLaunchKernelGGL(k_crops_sums<true>, dim3(nbands), dim3(CROP_THREADS), 0, st, S, 1, (const int32_t *)(d + RP_NA_O_GEO),
                        (const long long *)(d + RP_NA_O_LL), (const long long *)(d + RP_NA_O_LL + 16), (const int32_t *)nullptr, img, img,
                        c0, c0 + (size_t)w * h, c0 + (size_t)2 * w * h, d_sums, (const long long *)(d + RP_NA_O_LL + 32),
-                       (int32_t *)(d + RP_NA_O_EXT), (const int32_t *)(d + RP_NA_O_BOBJ), mask);
+                       (int32_t *)(d + RP_NA_O_EXT), (const int32_t *)(d + RP_NA_O_BOBJ), mask, (const int32_t *)nullptr);
     hipLaunchKernelGGL(k_convex, dim3(1), dim3(128), lds, st, 1, (const int32_t *)(d + RP_NA_O_GEO), (const long long *)(d + RP_NA_O_LL + 32),
                        (const int32_t *)(d + RP_NA_O_EXT), d_sums, 0, h);
     HIPCHK(hipGetLastError());
