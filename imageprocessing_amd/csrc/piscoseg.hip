@@ -859,13 +859,30 @@ __global__ __launch_bounds__(256) void k_band_label(SegState S)
 #define SCAN_AGG (1ull << 62)
 #define SCAN_INC (2ull << 62)
 #define SCAN_SPIN_MAX (1 << 22)
+#ifndef LB_K
+#define LB_K 1                        // look-back windows (of 256 predecessor blocks) read per round (4: 0.179 ms against 0.157 ms)
+#endif
 // CAP = runs a band may hold for the LDS labelling: 1024 (15 KB of LDS, 7 blocks per CU) for ordinary frames, BAND_CAP_DENSE
 // (57 KB, 2 blocks per CU) for dense ones -- the host moves to the larger class when a batch's largest band asks for it
 #define BAND_CAP_DENSE 4096
+#ifdef BAND_PROF
+// -DBAND_PROF: thread 0 of every block adds the time (wall_clock64 ticks of 10 ns) it spent in each phase of k_runs_band;
+// pseg_destroy prints the averages.  Not part of the product build.
+__device__ unsigned long long g_band_prof[16];
+#define BAND_STAMP(k) do { if (threadIdx.x == 0) { const unsigned long long now_ = wall_clock64(); dt_[k] = (uint32_t)(now_ - stamp_); stamp_ = now_; \
+                           if ((k) == 5) for (int q_ = 0; q_ < 6; q_++) atomicAdd(&g_band_prof[q_], (unsigned long long)dt_[q_]); } } while (0)
+#else
+#define BAND_STAMP(k) do { } while (0)
+#endif
 template <int WPL, int CAP>
 __global__ __launch_bounds__(256) void k_runs_band(SegState S, int wpl, uint32_t cap, unsigned long long *__restrict__ scan,
                                                    uint32_t *__restrict__ bandmax)
 {
+#ifdef BAND_PROF
+    unsigned long long stamp_ = wall_clock64();
+    uint32_t dt_[6] = {0, 0, 0, 0, 0, 0};
+    if (threadIdx.x == 0) atomicAdd(&g_band_prof[15], 1ull);
+#endif
     __shared__ uint32_t lx[CAP];                          // run_x of the band's runs
     __shared__ uint16_t ly[CAP];                          // band-local row of every run
     __shared__ int fgp[CAP], bgp[CAP + BAND_H];
@@ -875,6 +892,7 @@ __global__ __launch_bounds__(256) void k_runs_band(SegState S, int wpl, uint32_t
     const int H = S.H, nbpf = (H + BAND_H - 1) / BAND_H;
     if (threadIdx.x == 0) s_ticket = (uint32_t)atomicAdd(&scan[0], 1ull);
     __syncthreads();
+    BAND_STAMP(0);                                        // ticket
     const int t = (int)s_ticket;
     const int f = t / nbpf, band = t - f * nbpf, y0 = band * BAND_H;
     const int nr = (y0 + BAND_H <= H) ? BAND_H : H - y0;  // rows in this band
@@ -900,6 +918,7 @@ __global__ __launch_bounds__(256) void k_runs_band(SegState S, int wpl, uint32_t
     const uint32_t incl = wave_scan_incl(cnt);            // lane order = (row, quarter) = raster order
     if (lane == 63) wtot[wv] = incl;
     __syncthreads();
+    BAND_STAMP(1);                                        // bit plane loaded, runs counted
     uint32_t wbase = 0;
     for (int w = 0; w < wv; w++) wbase += wtot[w];
     const uint32_t nb = wtot[0] + wtot[1] + wtot[2] + wtot[3];
@@ -941,6 +960,7 @@ __global__ __launch_bounds__(256) void k_runs_band(SegState S, int wpl, uint32_t
     };
     if (fits && cnt) emit_runs([&](uint32_t i, uint32_t rx) { lx[i] = rx; ly[i] = (uint16_t)yl; });
     __syncthreads();
+    BAND_STAMP(2);                                        // runs in LDS
     // global background index of the band's first gap.  That gap (the leading gap of the band's first row) touches the
     // padding column x = -1, so it stands for the frame-connected background (the virtual node -1) of this band; the
     // representatives of a frame's bands are united by k_unions_rows across the band boundaries, and the smallest one is
@@ -982,36 +1002,43 @@ __global__ __launch_bounds__(256) void k_runs_band(SegState S, int wpl, uint32_t
         }
         __syncthreads();
     }
+    BAND_STAMP(3);                                        // labelled
     // decoupled look-back, after the labelling (most predecessors know their inclusive prefix by now): the whole block
     // reads 256 predecessor states per round, every wave sums its 64 up to the nearest inclusive one
-    __shared__ uint32_t lb_sum[4], lb_hit[4];
+    __shared__ uint32_t lb_sum[4 * LB_K], lb_hit[4 * LB_K];
     if (t > 0) {
         uint32_t excl = 0;
         int pos = t - 1;
         bool timeout = false;
         for (;;) {
-            const int idx = pos - (int)threadIdx.x;
-            unsigned long long sv = SCAN_INC;               // before block 0: inclusive prefix 0
-            if (idx >= 0) {
-                int spins = 0;
-                for (;;) {
-                    sv = __hip_atomic_load(&scan[2 + idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if ((sv >> 62) != 0 || ++spins >= SCAN_SPIN_MAX) break;
-                    __builtin_amdgcn_s_sleep(2);
-                }
-                if ((sv >> 62) == 0) { timeout = true; sv = SCAN_INC; }      // never expected; the host reports it
+            // LB_K windows of 256 predecessors per round, all loads in flight together
+            unsigned long long sv[LB_K];
+#pragma unroll
+            for (int k = 0; k < LB_K; k++) {
+                const int idx = pos - 256 * k - (int)threadIdx.x;
+                sv[k] = idx >= 0 ? __hip_atomic_load(&scan[2 + idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : SCAN_INC;   // before block 0: inclusive prefix 0
             }
-            const unsigned long long incm = __ballot((sv >> 62) == 2);
-            const int L = incm ? (int)__builtin_ctzll(incm) : 64;
-            const uint32_t part_sum = wave_sum63(lane <= L ? (uint32_t)sv : 0u);
-            if (lane == 63) { lb_sum[wv] = part_sum; lb_hit[wv] = incm != 0; }
+#pragma unroll
+            for (int k = 0; k < LB_K; k++) {
+                const int idx = pos - 256 * k - (int)threadIdx.x;
+                int spins = 0;
+                while ((sv[k] >> 62) == 0 && ++spins < SCAN_SPIN_MAX) {
+                    __builtin_amdgcn_s_sleep(2);
+                    sv[k] = __hip_atomic_load(&scan[2 + idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if ((sv[k] >> 62) == 0) { timeout = true; sv[k] = SCAN_INC; }   // never expected; the host reports it
+                const unsigned long long incm = __ballot((sv[k] >> 62) == 2);
+                const int L = incm ? (int)__builtin_ctzll(incm) : 64;
+                const uint32_t part_sum = wave_sum63(lane <= L ? (uint32_t)sv[k] : 0u);
+                if (lane == 63) { lb_sum[4 * k + wv] = part_sum; lb_hit[4 * k + wv] = incm != 0; }
+            }
             if (timeout) bandmax[1] = 1;
             __syncthreads();
             bool hit = false;
-            for (int w = 0; w < 4 && !hit; w++) { excl += lb_sum[w]; hit = lb_hit[w] != 0; }
+            for (int w = 0; w < 4 * LB_K && !hit; w++) { excl += lb_sum[w]; hit = lb_hit[w] != 0; }
             __syncthreads();
             if (hit) break;
-            pos -= 256;
+            pos -= 256 * LB_K;
         }
         if (threadIdx.x == 0) {
             s_base = excl;
@@ -1019,6 +1046,7 @@ __global__ __launch_bounds__(256) void k_runs_band(SegState S, int wpl, uint32_t
         }
         __syncthreads();
     }
+    BAND_STAMP(4);                                        // look-back
     const int R0 = (int)s_base;                           // global index of the band's first run
     // (cap == 0: the tables do not exist yet -- not even the background entries every row owns without any run)
     const bool room = cap > 0 && (unsigned long long)R0 + nb <= (unsigned long long)cap;
@@ -1053,6 +1081,7 @@ __global__ __launch_bounds__(256) void k_runs_band(SegState S, int wpl, uint32_t
         const int g = lrow[yy + 1] + yy;
         S.bg_left[Bb + g] = lrow[yy + 1] == lrow[yy] ? -1 : R0 + lrow[yy + 1] - 1;
     }
+    BAND_STAMP(5);                                        // published (stores issued)
 }
 
 // flatten + enclosure tree in one launch: every parent is followed to its root on the fly (the parents other threads
@@ -2057,6 +2086,17 @@ extern "C" int pseg_destroy(pseg_ctx *ctx)
     async_stop(ctx);
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
+#ifdef BAND_PROF
+    {
+        unsigned long long p[16] = {0};
+        if (hipMemcpyFromSymbol(p, HIP_SYMBOL(g_band_prof), sizeof p) == hipSuccess && p[15]) {
+            fprintf(stderr, "k_runs_band phases, us per block over %llu blocks:", p[15]);
+            const char *nm[6] = {"ticket", "load+count", "runs->LDS", "label", "look-back", "publish"};
+            for (int k = 0; k < 6; k++) fprintf(stderr, " %s %.2f", nm[k], 0.01 * (double)p[k] / (double)p[15]);
+            fprintf(stderr, "\n");
+        }
+    }
+#endif
     DevBuf *bufs[] = {&ctx->bits, &ctx->partials, &ctx->maskpart, &ctx->head, &ctx->outpack, &ctx->rowspans, &ctx->rowcnt,
                       &ctx->rowoff, &ctx->framebase, &ctx->scan_state, &ctx->run_x, &ctx->run_fy, &ctx->fg_parent, &ctx->ext, &ctx->gapl, &ctx->runlabel,
                       &ctx->bg_parent, &ctx->bg_left, &ctx->minx, &ctx->maxx, &ctx->maxy, &ctx->area2,
