@@ -96,7 +96,7 @@ struct pseg_ctx {
     int n_saved = 0;
     // host views of the last table (page-locked tail buffer): rows [10][t_hr], saved_row, crop_off
     const int32_t *t_rows = nullptr, *t_saved_row = nullptr; const int64_t *t_crop_off = nullptr; size_t t_hr = 1;
-    int band_cap = 1024, band_calm = 0;   // LDS size class of k_runs_band (BAND_CAP / BAND_CAP_DENSE) and calls since it was needed
+    int band_cap = 1024, band_calm = 0;   // LDS size class of k_runs_band (BAND_CAP / _MID / _DENSE) and calm calls in a row
     int spec_hold = 0;            // calls for which the fast path stays off (after a batch too dense for the LDS labelling)
     size_t runcap = 0;            // runs the tables are sized for: the labelling chain is queued against it without a host round trip
     struct AsyncWorker *worker = nullptr;   // pseg_submit / pseg_wait: the context's own host thread (started on first use)
@@ -862,8 +862,10 @@ __global__ __launch_bounds__(256) void k_band_label(SegState S)
 #ifndef LB_K
 #define LB_K 1                        // look-back windows (of 256 predecessor blocks) read per round (4: 0.179 ms against 0.157 ms)
 #endif
-// CAP = runs a band may hold for the LDS labelling: 1024 (15 KB of LDS, 7 blocks per CU) for ordinary frames, BAND_CAP_DENSE
-// (57 KB, 2 blocks per CU) for dense ones -- the host moves to the larger class when a batch's largest band asks for it
+// CAP = runs a band may hold for the LDS labelling: 1024 (15 KB of LDS, 8 blocks per CU) for ordinary frames, BAND_CAP_MID
+// (29 KB, 5 blocks per CU) and BAND_CAP_DENSE (57 KB, 2 blocks per CU) for dense ones -- the host moves to the class a batch's
+// largest band asks for, and back down after 8 batches that would have fitted the smaller one with a third to spare
+#define BAND_CAP_MID 2048
 #define BAND_CAP_DENSE 4096
 #ifdef BAND_PROF
 // -DBAND_PROF: thread 0 of every block adds the time (wall_clock64 ticks of 10 ns) it spent in each phase of k_runs_band;
@@ -2495,11 +2497,18 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
         return 0;
     };
     auto launch_fused = [&](uint32_t capv) {
-        const bool dense = ctx->band_cap > BAND_CAP;
-        if (runs_wpl > 10 && dense) hipLaunchKernelGGL((k_runs_band<16, BAND_CAP_DENSE>), dim3(nbpf * n), dim3(256), 0, ctx->cur, S, runs_wpl, capv, scan, bandmax_d);
-        else if (runs_wpl > 10) hipLaunchKernelGGL((k_runs_band<16, BAND_CAP>), dim3(nbpf * n), dim3(256), 0, ctx->cur, S, runs_wpl, capv, scan, bandmax_d);
-        else if (dense) hipLaunchKernelGGL((k_runs_band<10, BAND_CAP_DENSE>), dim3(nbpf * n), dim3(256), 0, ctx->cur, S, runs_wpl, capv, scan, bandmax_d);
-        else hipLaunchKernelGGL((k_runs_band<10, BAND_CAP>), dim3(nbpf * n), dim3(256), 0, ctx->cur, S, runs_wpl, capv, scan, bandmax_d);
+        const dim3 g(nbpf * n), b(256);
+#define BAND_LAUNCH(WPL_, CAP_) hipLaunchKernelGGL((k_runs_band<WPL_, CAP_>), g, b, 0, ctx->cur, S, runs_wpl, capv, scan, bandmax_d)
+        if (runs_wpl > 10) {
+            if (ctx->band_cap > BAND_CAP_MID) BAND_LAUNCH(16, BAND_CAP_DENSE);
+            else if (ctx->band_cap > BAND_CAP) BAND_LAUNCH(16, BAND_CAP_MID);
+            else BAND_LAUNCH(16, BAND_CAP);
+        } else {
+            if (ctx->band_cap > BAND_CAP_MID) BAND_LAUNCH(10, BAND_CAP_DENSE);
+            else if (ctx->band_cap > BAND_CAP) BAND_LAUNCH(10, BAND_CAP_MID);
+            else BAND_LAUNCH(10, BAND_CAP);
+        }
+#undef BAND_LAUNCH
         if (H > BAND_H) hipLaunchKernelGGL(k_unions_rows, dim3((H - 1) / BAND_H, n), dim3(64), 0, ctx->cur, S, BAND_H, capv, (uint32_t)ctx->band_cap);
     };
     // from the flattening to the size scans; gridded for `runs` runs, guarded by (cap, bcap) on the device
@@ -2620,8 +2629,13 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
     // size class of the band kernel for the next call: the large tables as soon as a band asked for them, the small ones
     // again after 8 calls that would have fitted with room to spare
     ctx->dense_rows = (size_t)nfg >= (size_t)n * H * FILL_ROWS_MIN;
-    if (band_seen > BAND_CAP) { ctx->band_cap = BAND_CAP_DENSE; ctx->band_calm = 0; }
-    else if (ctx->band_cap > BAND_CAP && band_seen <= BAND_CAP * 3 / 4 && ++ctx->band_calm >= 8) { ctx->band_cap = BAND_CAP; ctx->band_calm = 0; }
+    {
+        auto class_for = [](uint32_t b) { return b <= BAND_CAP ? BAND_CAP : (b <= BAND_CAP_MID ? BAND_CAP_MID : BAND_CAP_DENSE); };
+        const int need = class_for(band_seen), roomy = class_for(band_seen + band_seen / 3);
+        if (need > ctx->band_cap) { ctx->band_cap = need; ctx->band_calm = 0; }
+        else if (roomy < ctx->band_cap) { if (++ctx->band_calm >= 8) { ctx->band_cap = roomy; ctx->band_calm = 0; } }
+        else ctx->band_calm = 0;
+    }
     ctx->head_on_host = true;
     const HeadHost hh = head_host(ctx, n);
     const uint32_t *h_ftot3 = hh.ftot3, *h_rowbase = hh.rowbase, *h_savedbase = hh.savedbase;
