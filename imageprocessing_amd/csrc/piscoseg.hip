@@ -1240,39 +1240,62 @@ __global__ __launch_bounds__(256) void k_scan_small(const uint32_t *in, uint32_t
     if (threadIdx.x == 0) out[(size_t)F * stride_out] = carry;
 }
 
-// ranks of external roots / kept / saved objects inside each frame (block per frame).
+// ranks of external roots / kept / saved objects inside each frame (block per frame; a thread takes RANK_IPT consecutive
+// runs per round, the three counts of a thread travel through the wave scan packed in one register).
 // ftot3[f*3+{0,1,2}] = number of external contours, kept, saved.
+#define RANK_IPT 4
 __global__ __launch_bounds__(1024) void k_rank(SegState S, double min_seg, double min_save, uint32_t *ftot3, uint32_t cap, uint32_t bcap)
 {
-    __shared__ uint32_t wtot[16][3];
+    __shared__ uint32_t wtot[16];                         // per wave: the three totals, 10 bits each (<= 64 * RANK_IPT)
     __shared__ uint32_t carry[3];
     if (!chain_ok(S, cap, bcap)) return;
     const int f = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int r0 = (int)S.framebase[f], r1 = (int)S.framebase[f + 1];
     if (threadIdx.x < 3) carry[threadIdx.x] = 0;
     __syncthreads();
-    const unsigned long long below = (1ull << lane) - 1ull;
-    for (int base = r0; base < r1; base += 1024) {
-        const int r = base + threadIdx.x;
-        bool v0 = false, v1 = false, v2 = false;
-        if (r < r1 && is_ext_root(S, r)) {
-            const double area = 0.5 * (double)S.area2[r];
-            v0 = true;
-            v1 = !(area < min_seg);                         // detection.py:223 ("< -> continue")
-            v2 = v1 && (area > min_save);                   // detection.py:235
-        }
-        const unsigned long long b0 = __ballot(v0), b1 = __ballot(v1), b2 = __ballot(v2);
-        if (lane == 0) { wtot[wv][0] = (uint32_t)__popcll(b0); wtot[wv][1] = (uint32_t)__popcll(b1); wtot[wv][2] = (uint32_t)__popcll(b2); }
+    for (int base = r0; base < r1; base += 1024 * RANK_IPT) {
+        const int r = base + RANK_IPT * (int)threadIdx.x;
+        const bool full = r + RANK_IPT <= r1;
+        int fp[RANK_IPT], ex[RANK_IPT];
+        if (full) { __builtin_memcpy(fp, S.fg_parent + r, 4 * RANK_IPT); __builtin_memcpy(ex, S.ext + r, 4 * RANK_IPT); }
+        else
+#pragma unroll
+            for (int j = 0; j < RANK_IPT; j++) { fp[j] = r + j < r1 ? S.fg_parent[r + j] : -1; ex[j] = r + j < r1 ? S.ext[r + j] : -1; }
+        uint32_t m0 = 0, m1 = 0, m2 = 0;                    // bit j: run r + j is an external root / kept / saved
+#pragma unroll
+        for (int j = 0; j < RANK_IPT; j++)
+            if (fp[j] == r + j && ex[j] == r + j) {         // is_ext_root
+                const double area = 0.5 * (double)S.area2[r + j];
+                const bool v1 = !(area < min_seg);          // detection.py:223 ("< -> continue")
+                m0 |= 1u << j; m1 |= (uint32_t)v1 << j; m2 |= (uint32_t)(v1 && area > min_save) << j;   // detection.py:235
+            }
+        const uint32_t packed = (uint32_t)__popc(m0) | ((uint32_t)__popc(m1) << 10) | ((uint32_t)__popc(m2) << 20);
+        const uint32_t incl = wave_scan_incl(packed);
+        if (lane == 63) wtot[wv] = incl;
         __syncthreads();
         uint32_t p0 = carry[0], p1 = carry[1], p2 = carry[2];
-        for (int w = 0; w < wv; w++) { p0 += wtot[w][0]; p1 += wtot[w][1]; p2 += wtot[w][2]; }
-        if (r < r1) {
-            S.extrank[r] = (int32_t)(p0 + (uint32_t)__popcll(b0 & below));
-            S.keptrank[r] = (int32_t)(p1 + (uint32_t)__popcll(b1 & below));
-            S.savedrank[r] = (int32_t)(p2 + (uint32_t)__popcll(b2 & below));
+        for (int w = 0; w < wv; w++) { const uint32_t t = wtot[w]; p0 += t & 0x3ffu; p1 += (t >> 10) & 0x3ffu; p2 += t >> 20; }
+        const uint32_t excl = incl - packed;
+        int o0[RANK_IPT], o1[RANK_IPT], o2[RANK_IPT];
+#pragma unroll
+        for (int j = 0; j < RANK_IPT; j++) {
+            const uint32_t below = (1u << j) - 1u;
+            o0[j] = (int)(p0 + (excl & 0x3ffu) + (uint32_t)__popc(m0 & below));
+            o1[j] = (int)(p1 + ((excl >> 10) & 0x3ffu) + (uint32_t)__popc(m1 & below));
+            o2[j] = (int)(p2 + (excl >> 20) + (uint32_t)__popc(m2 & below));
         }
+        if (full) {
+            __builtin_memcpy(S.extrank + r, o0, 4 * RANK_IPT); __builtin_memcpy(S.keptrank + r, o1, 4 * RANK_IPT);
+            __builtin_memcpy(S.savedrank + r, o2, 4 * RANK_IPT);
+        } else
+#pragma unroll
+            for (int j = 0; j < RANK_IPT; j++)
+                if (r + j < r1) { S.extrank[r + j] = o0[j]; S.keptrank[r + j] = o1[j]; S.savedrank[r + j] = o2[j]; }
         __syncthreads();
-        if (threadIdx.x == 1023) { carry[0] = p0 + wtot[15][0]; carry[1] = p1 + wtot[15][1]; carry[2] = p2 + wtot[15][2]; }
+        if (threadIdx.x == 1023) {
+            const uint32_t t = wtot[15];
+            carry[0] = p0 + (t & 0x3ffu); carry[1] = p1 + ((t >> 10) & 0x3ffu); carry[2] = p2 + (t >> 20);
+        }
         __syncthreads();
     }
     if (threadIdx.x < 3) ftot3[f * 3 + threadIdx.x] = carry[threadIdx.x];
