@@ -361,8 +361,10 @@ __device__ __forceinline__ uint32_t gather4(uint32_t r)     // bits 7,15,23,31 -
 }
 // frame s: cleaned = 255 - |img - bg| (bg_correction.py:80-81), the four sums and the threshold bits
 // (detection.py:178-202).  c = px_split(img).  en is wave-uniform; a disabled call stores into the trash rows.
+// The four sums of the frame are left per lane in (op, os1, os3) -- sum x | sum c << 16, sum x^2, sum c^2 --; bg_flush
+// reduces them over the wave for four frames at a time.
 template <bool PAD>
-__device__ __forceinline__ void bg_emit(const BgEmit &E, uint2 img, Px8 c, Px8 bg, int s, bool en)
+__device__ __forceinline__ void bg_emit(const BgEmit &E, uint2 img, Px8 c, Px8 bg, int s, bool en, uint32_t &op, uint32_t &os1, uint32_t &os3)
 {
     uint32_t de0 = pksub(pkmax(c.e0, bg.e0), pkmin(c.e0, bg.e0)), do0 = pksub(pkmax(c.o0, bg.o0), pkmin(c.o0, bg.o0));
     uint32_t de1 = pksub(pkmax(c.e1, bg.e1), pkmin(c.e1, bg.e1)), do1 = pksub(pkmax(c.o1, bg.o1), pkmin(c.o1, bg.o1));
@@ -372,7 +374,6 @@ __device__ __forceinline__ void bg_emit(const BgEmit &E, uint2 img, Px8 c, Px8 b
     const bool real = PAD ? (en && E.act) : en;           // without padding lanes the bases stay wave-uniform (scalar registers)
     uint8_t *pc = real ? E.cleaned + (size_t)s * E.P : E.t_cleaned;          // wave-uniform bases, 32-bit lane offsets
     uint8_t *pb = real ? E.bits8 + (size_t)s * (E.P / 8) : E.t_bits8;
-    uint4 *pp = en ? E.partials + (size_t)s * E.nwaves : E.t_partials;
 
     // streamed out: a plain store would leave 1.3 GB of dirty lines to drain from L2 under the kernels that follow
     {
@@ -396,13 +397,40 @@ __device__ __forceinline__ void bg_emit(const BgEmit &E, uint2 img, Px8 c, Px8 b
     const uint32_t b = __builtin_amdgcn_udot4(f1, 0x80402010u, __builtin_amdgcn_udot4(f0, 0x08040201u, 0u, false), false) >> 7;
     if (PAD) pb[E.strip32] = (uint8_t)b;
     else __builtin_amdgcn_raw_buffer_store_b8((uint8_t)b, raw_rsrc(pb), (int)E.strip32, 0, 0);
-    // wave sums, valid in lane 63: sum x and sum c (<= 2040 per lane) travel packed in one register until the last step
-    uint32_t p = s0 | (s2 << 16);
-    p = dpp_add<0x111, 0xf>(p); p = dpp_add<0x112, 0xf>(p); p = dpp_add<0x114, 0xf>(p); p = dpp_add<0x118, 0xf>(p);
-    p = dpp_add<0x142, 0xa>(p);                                            // <= 65280 per half: no carry yet
-    const uint32_t q = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p, 0x143, 0xc, 0xf, false);
-    s1 = wave_sum63(s1); s3 = wave_sum63(s3);
-    if ((threadIdx.x & 63) == 63) pp[E.wave] = make_uint4((p & 0xffffu) + (q & 0xffffu), s1, (p >> 16) + (q >> 16), s3);
+    op = s0 | (s2 << 16);                                   // sum x and sum c (<= 2040 per lane) travel packed in one register
+    os1 = s1; os3 = s3;
+}
+// Wave sums of four frames at once.  Two swap levels put frame r into row r of the wave (v_permlane32_swap exchanges the
+// upper half of one register with the lower half of another, v_permlane16_swap the odd rows with the even rows: swap + add
+// halves two registers into one, each lane then holds the sum over the four rows at its position), four row_shr levels sum
+// the 16 lanes of a row: lanes 15 / 31 / 47 / 63 hold the totals of frames s0 .. s0+3 and store them.  30 vector
+// instructions for four frames and three registers instead of 19 per frame.
+// Frame s0 + r is stored for r < cnt and lo <= s0 + r < hi; the others go to the trash rows.
+typedef unsigned int u32pair_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t rows_of_frames(uint32_t f0, uint32_t f1, uint32_t f2, uint32_t f3)
+{
+    const u32pair_t a = __builtin_amdgcn_permlane32_swap(f0, f2, false, false);      // [f0 lo, f2 lo], [f0 hi, f2 hi]
+    const u32pair_t b = __builtin_amdgcn_permlane32_swap(f1, f3, false, false);
+    const uint32_t x = a[0] + a[1], y = b[0] + b[1];        // rows 0,1: f0 (f1); rows 2,3: f2 (f3)
+    const u32pair_t c = __builtin_amdgcn_permlane16_swap(x, y, false, false);         // [x0, y0, x2, y2], [x1, y1, x3, y3]
+    return c[0] + c[1];                                      // row r: frame r, summed over the four rows
+}
+struct BgSums { uint32_t p[4], s1[4], s3[4]; };
+__device__ __forceinline__ void bg_flush(const BgEmit &E, const BgSums &A, int s0, int lo, int hi, int cnt)
+{
+    uint32_t p = rows_of_frames(A.p[0], A.p[1], A.p[2], A.p[3]);
+    uint32_t s1 = rows_of_frames(A.s1[0], A.s1[1], A.s1[2], A.s1[3]);
+    uint32_t s3 = rows_of_frames(A.s3[0], A.s3[1], A.s3[2], A.s3[3]);
+    p = dpp_add<0x111, 0xf>(p); p = dpp_add<0x112, 0xf>(p); p = dpp_add<0x114, 0xf>(p);     // <= 8 * 4 * 2040 per half: no carry yet
+    const uint32_t q = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p, 0x118, 0xf, 0xf, false);
+    s1 = dpp_add<0x111, 0xf>(s1); s1 = dpp_add<0x112, 0xf>(s1); s1 = dpp_add<0x114, 0xf>(s1); s1 = dpp_add<0x118, 0xf>(s1);
+    s3 = dpp_add<0x111, 0xf>(s3); s3 = dpp_add<0x112, 0xf>(s3); s3 = dpp_add<0x114, 0xf>(s3); s3 = dpp_add<0x118, 0xf>(s3);
+    const int lane = threadIdx.x & 63, r = lane >> 4, fr = s0 + r;
+    if ((lane & 15) == 15) {
+        const bool ok = r < cnt && fr >= lo && fr < hi;
+        uint4 *pp = ok ? E.partials + (size_t)fr * E.nwaves : E.t_partials;
+        pp[E.wave] = make_uint4((p & 0xffffu) + (q & 0xffffu), s1, (p >> 16) + (q >> 16), s3);
+    }
 }
 
 // Per-thread state.  The 12-frame history of raw pixels lives in an LDS ring (dynamic slot index,
@@ -412,6 +440,7 @@ struct BgRegs {
     uint2 pf[4];           // frames k .. k+3 (pf[PH] is the frame of the current step)
     Px8 prev;              // frame k-1, split
     Px8 mp, t2[2], t4[4], t8[4], last;
+    BgSums acc;            // per-lane sums of the frames emitted by the last (up to) four steps
 };
 #define BG_SLOTS 16
 template <int PH, bool PAD>
@@ -432,7 +461,7 @@ __device__ __forceinline__ void bg_step(BgRegs &R, uint2 *ring, const BgEmit &E,
     Px8 t8 = px_max(t4, R.t4[(PH + 3) & 3]); R.t4[(PH + 3) & 3] = t4;
     Px8 t11 = px_max(t8, R.t8[PH & 3]); R.t8[(PH + 3) & 3] = t8;
     R.last = t11;
-    bg_emit<PAD>(E, old, px_split(old), t11, k - 11, k - 11 >= a && k < n - 1);
+    bg_emit<PAD>(E, old, px_split(old), t11, k - 11, k - 11 >= a && k < n - 1, R.acc.p[PH], R.acc.s1[PH], R.acc.s3[PH]);
 }
 
 // grid = (ceil(P/2048), chunks); chunk c emits frames [bounds[c], bounds[c+1]) of the reference batch that ends at frame
@@ -496,15 +525,24 @@ __global__ __launch_bounds__(256, 4) void k_bg_stream(const uint8_t *__restrict_
         bg_step<1, PAD>(R, ring, E, src, k + 1, a, kend, n);
         bg_step<2, PAD>(R, ring, E, src, k + 2, a, kend, n);
         bg_step<3, PAD>(R, ring, E, src, k + 3, a, kend, n);
+        bg_flush(E, R.acc, k - 11, a, n - 12, 4);           // (step k emits frame k - 11, stored while a <= k - 11 and k < n - 1)
     }
-    if (k <= kend) bg_step<0, PAD>(R, ring, E, src, k, a, kend, n);
-    if (k + 1 <= kend) bg_step<1, PAD>(R, ring, E, src, k + 1, a, kend, n);
-    if (k + 2 <= kend) bg_step<2, PAD>(R, ring, E, src, k + 2, a, kend, n);
+    if (k <= kend) {
+        const int left = kend - k + 1;                      // 1 .. 3 steps
+        bg_step<0, PAD>(R, ring, E, src, k, a, kend, n);
+        if (left > 1) bg_step<1, PAD>(R, ring, E, src, k + 1, a, kend, n);
+        if (left > 2) bg_step<2, PAD>(R, ring, E, src, k + 2, a, kend, n);
+        bg_flush(E, R.acc, k - 11, a, n - 12, left);
+    }
     if (b == n) {                                           // the last 12 frames share bg[n-12] = T11 of the final step;
 #pragma unroll 1
-        for (int i = n - 12; i < n; i++) {                   // their raw pixels are still in the ring (a <= n - 12)
-            const uint2 img = ring[(i & (BG_SLOTS - 1)) * 256];
-            bg_emit<PAD>(E, img, px_split(img), R.last, i, true);
+        for (int i = n - 12; i < n; i += 4) {                // their raw pixels are still in the ring (a <= n - 12)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint2 img = ring[((i + j) & (BG_SLOTS - 1)) * 256];
+                bg_emit<PAD>(E, img, px_split(img), R.last, i + j, true, R.acc.p[j], R.acc.s1[j], R.acc.s3[j]);
+            }
+            bg_flush(E, R.acc, i, n - 12, n, 4);
         }
     }
 }
