@@ -13,7 +13,7 @@ NSUMS = 24
 SYMBOLS = [
     "pseg_create", "pseg_destroy", "pseg_last_error", "pseg_set_stream", "pseg_bgcorrect", "pseg_detect",
     "pseg_process", "pseg_process_part", "pseg_process_batches", "pseg_submit", "pseg_wait", "pseg_fetch_crops", "pseg_regionprops", "pseg_regionprops_noalloc", "pseg_vit_tensors",
-    "pseg_disk_mask", "pseg_resize_frames", "pseg_synth_frames", "pseg_last_ms",
+    "pseg_disk_mask", "pseg_resize_frames", "pseg_synth_frames", "pseg_last_ms", "pseg_tuning_state",
 ]
 
 
@@ -85,6 +85,8 @@ def load():
     L.pseg_synth_frames.argtypes = [vp, i32, i32, C.c_uint64, vp, vp, vp]
     L.pseg_last_ms.argtypes = [vp, i32]
     L.pseg_last_ms.restype = C.c_float
+    L.pseg_tuning_state.argtypes = [vp, i32]
+    L.pseg_tuning_state.restype = C.c_longlong
     for f in ("pseg_create", "pseg_destroy", "pseg_set_stream", "pseg_bgcorrect", "pseg_detect", "pseg_process", "pseg_process_part", "pseg_process_batches", "pseg_submit", "pseg_wait",
               "pseg_fetch_crops", "pseg_regionprops", "pseg_regionprops_noalloc", "pseg_vit_tensors", "pseg_disk_mask", "pseg_resize_frames", "pseg_synth_frames"):
         getattr(L, f).restype = i32

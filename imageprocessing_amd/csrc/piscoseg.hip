@@ -2178,6 +2178,17 @@ extern "C" int pseg_destroy(pseg_ctx *ctx)
 
 extern "C" const char *pseg_last_error(const pseg_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 extern "C" float pseg_last_ms(const pseg_ctx *ctx, int which) { return (ctx && which >= 0 && which < 6) ? ctx->ms[which] : -1.f; }
+extern "C" long long pseg_tuning_state(const pseg_ctx *ctx, int which)
+{
+    if (!ctx) return -1;
+    switch (which) {
+    case 0: return (long long)ctx->runcap;
+    case 1: return ctx->band_cap;
+    case 2: return ctx->spec_hold;
+    case 3: return ctx->fill_rows >= 0 ? (ctx->fill_rows > 0) : (ctx->dense_rows ? 1 : 0);
+    default: return -1;
+    }
+}
 
 extern "C" int pseg_set_stream(pseg_ctx *ctx, void *hip_stream)
 {

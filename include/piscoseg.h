@@ -192,6 +192,14 @@ int pseg_synth_frames(pseg_ctx *ctx, int n, int frame0, uint64_t seed, const int
  * 3 = label-map write, 4 = masks + crops + sums, 5 = whole call. */
 float pseg_last_ms(const pseg_ctx *ctx, int which);
 
+/* What the context has adapted to over the batches it has seen (no counterpart in the reference; for tests and
+ * diagnosis): 0 = capacity of the run tables (runs; the labelling chain is queued without a host round trip while a
+ * batch stays below it), 1 = size class of the band kernel (runs a 64-row band may hold for the labelling in LDS:
+ * 1024, 2048 or 4096), 2 = calls for which the chain is queued only after the run count is known (after a batch too dense
+ * even for the largest class), 3 = 1 when the next label map is written row-wise (dense rows), 0 span-wise.
+ * Returns -1 for a bad argument. */
+long long pseg_tuning_state(const pseg_ctx *ctx, int which);
+
 #ifdef __cplusplus
 }
 #endif

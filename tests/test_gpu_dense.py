@@ -105,3 +105,55 @@ def test_dense_fullsize(cfg_name):
         assert nrows == rows[2] and nsaved == saved[2]
     finally:
         seg.close()
+
+
+def test_density_changes_between_batches():
+    """One context sees batches of very different density one after the other: what it has adapted to (run-table capacity,
+    LDS size class of the band kernel, slow path, row-wise label fill: pseg_tuning_state) follows, and every batch equals the
+    oracle -- the batch that finds the tables too small or its bands beyond the current class is repeated inside the call."""
+    import torch
+    from imageprocessing_amd.engine import Segmenter
+    H, W, n = 256, 512, 7
+    seg = Segmenter(H, W, max_frames=n, device=0)
+    rng = np.random.default_rng(17)
+
+    def noise(p):
+        c = np.full((n, H, W), 255, np.uint8)
+        for f in range(n):
+            c[f][rng.random((H, W)) < p] = rng.integers(0, 240, 1, dtype=np.uint8)[0]
+        return c
+
+    def blobs():
+        c = np.full((n, H, W), 255, np.uint8)
+        for f in range(n):
+            for _ in range(6):
+                y, x, h, w = rng.integers(0, H - 40), rng.integers(0, W - 60), rng.integers(5, 40), rng.integers(5, 60)
+                c[f, y:y + h, x:x + w] = rng.integers(0, 200)
+        return c
+
+    def run(cleaned):
+        items = [(cleaned[f], cleaned[f], [100.0, 50.0], f"d_{f:03d}.png") for f in range(n)]
+        dets = helpers.oracle_detect(items, None, min_area_to_segment=2, min_area_to_save=30, mask_img=False)
+        labels = torch.empty((n, H, W), dtype=torch.int32, device="cuda")
+        tab = seg.detect(torch.from_numpy(cleaned).cuda(), min_area_to_segment=2, min_area_to_save=30, labels=labels, fetch_crops=True)
+        helpers.compare_table(tab, dets, H, W, labels=labels.cpu().numpy())
+        return seg.tuning_state()
+
+    try:
+        st = run(blobs())
+        assert st["band_class"] == 1024 and not st["fill_by_rows"] and st["run_capacity"] > 0
+        cap0 = st["run_capacity"]
+        st = run(noise(0.02))                              # ~10 runs per row: more runs than the tables hold -> repeated; small class
+        assert st["run_capacity"] > cap0 and st["band_class"] == 1024 and st["fill_by_rows"]
+        st = run(noise(0.07))                              # ~33 runs per row, ~2100 per band
+        assert st["band_class"] in (2048, 4096)
+        st = run(noise(0.13))                              # ~58 runs per row, ~3700 per band
+        assert st["band_class"] == 4096 and st["slow_path_calls"] == 0
+        st = run(noise(0.5))                               # ~128 runs per row, ~8200 per band: global union-find, slow path for a while
+        assert st["band_class"] == 4096 and st["slow_path_calls"] > 0
+        st = run(noise(0.13))                              # still on the slow path, bands fit the large class again
+        for _ in range(20):                                # calm batches: back to the small class and the span-wise fill
+            st = run(blobs())
+        assert st["band_class"] == 1024 and st["slow_path_calls"] == 0 and not st["fill_by_rows"]
+    finally:
+        seg.close()
