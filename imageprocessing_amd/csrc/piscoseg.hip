@@ -3,7 +3,7 @@
 // Hot path of fannz00/ImageProcessing restated for MI355X:
 //   dense, HBM-bound:  k_bg_stream / k_bg_generic  (bg_correction.py:65-86 + detection.py:178-202)
 //                      k_threshold                  (detection.py:178-202 when cleaned comes from elsewhere)
-//                      k_label_fill                 (label map)
+//                      k_label_fill / k_label_fill_rows   (label map)
 //   sparse, on the 1-bit threshold plane: run extraction, union-find over runs, enclosure tree,
 //                      quad-count contour area, bbox, ordering (pseg_core.h; detection.py:204-216)
 //   per saved object:  cumulative filled mask window, three crops, integer sums behind the 32
@@ -75,9 +75,9 @@ struct pseg_ctx {
     DevBuf rows, saved_row, saved_geo, crop_off, bits_off, maskbits, crops_raw, crops_masked, crops_mask;
     bool mask_counted = false;    // maskcnt already holds the number of mask == 255 pixels (fused background kernel)
     bool have_bits = false;       // threshold plane + masked sums already produced by the bg kernel
-    DevBuf bounds, band_off, band_obj, trash, rp_small, rp_scratch, resize_tab, synth_objs, synth_off;
+    DevBuf bounds, band_off, band_obj /* one 64-byte descriptor per crop band: k_band_map */, trash, rp_small, rp_scratch, resize_tab, synth_objs, synth_off;
     int bounds_n = -1, bounds_emit = -1, bounds_chunks = -1, bounds_batch = -1;
-    bool runs_old = false;        // wave-per-row run extraction (k_runs) instead of k_runs_quad (PSEG_RUNS_OLD)
+    bool runs_old = false;        // PSEG_RUNS_OLD=1: two-pass run extraction (k_runs) + k_band_label instead of the fused k_runs_band
     bool exclusive = true;        // the device part of a call holds the GPU's turn (PSEG_EXCLUSIVE=0: batches interleave freely)
     bool shared_stream = false;   // PSEG_SHARED_STREAM=1: the streaming parts of all contexts go through one stream per device (GpuTurn)
     bool early_release = true;    // hand the turn on behind the label fill instead of behind the last kernel (PSEG_EARLY_RELEASE=0)
