@@ -95,3 +95,48 @@ def test_submit_wait_protocol_and_errors():
         seg.submit(frames, threshold=100)                  # closing with a call in flight waits for it
     finally:
         seg.close()
+
+
+def test_host_pipeline_from_host_memory_equals_synchronous_calls_and_the_oracle():
+    """engine.HostPipeline (what bench.py's host_input_fps times): batches that start in host memory -- a NumPy array, a
+    page-locked tensor, the producer writing into the staging buffer itself -- go up, through the fused path and back with
+    pinned crops, two contexts taking turns.  Every batch equals the oracle; batch order and slot reuse are exercised with
+    five batches of different lengths on two slots."""
+    import torch
+    from imageprocessing_amd import synth
+    from imageprocessing_amd.engine import HostPipeline
+    H, W = 192, 256
+    lens = [13, 20, 14, 20, 16]
+    stacks = []
+    for b, n in enumerate(lens):
+        objs, off = synth.make_objects(n, H, W, 40 + b, per_frame=10, dmin=10, dmax=60)
+        st = synth.render(n, H, W, 40 + b, objs, off)
+        if b == 2:
+            st[3] = 77                                     # a corrupt frame
+        stacks.append(st)
+    hmask = helpers.make_disk(H, W, 90)
+    pipe = HostPipeline(H, W, max_frames=20, device=0, depth=2, labels=True)
+    try:
+        mask = torch.from_numpy(hmask).cuda()
+
+        def batches():
+            for b, st in enumerate(stacks):
+                if b % 3 == 0:
+                    yield len(st), st                               # NumPy array: copied into the staging buffer
+                elif b % 3 == 1:
+                    yield len(st), torch.from_numpy(st).pin_memory()   # page-locked tensor: uploaded as it is
+                else:
+                    pipe.staging(b % 2)[:len(st)] = st              # the producer fills the slot itself
+                    yield len(st), None
+        seen = []
+        for b, cleaned, ms, valid, tab in pipe.run(batches(), mask=mask, fetch_crops="pinned", min_area_to_save=100.0):
+            seen.append(b)
+            n = lens[b]
+            assert cleaned.shape[0] == n
+            dets = helpers.oracle_detect(helpers.oracle_bgcorrect(stacks[b]), hmask, min_area_to_save=100)
+            helpers.compare_table(tab, dets, H, W, labels=pipe.labels[b % 2][:n].cpu().numpy())
+            if b == 2:
+                assert valid[3] == 0 and valid.sum() == n - 1
+        assert seen == list(range(len(lens)))
+    finally:
+        pipe.close()
