@@ -184,1917 +184,9 @@ static HeadHost head_host(const pseg_ctx *ctx, int n)
     return h;
 }
 
-// ------------------------------------------------------------------------------------------------
-// small device helpers
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    return v;
-}
-
-// four u32 block sums -> out[0..3] (thread 0 writes); blockDim.x == 256
-__device__ __forceinline__ void block_sum4_store(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t *out)
-{
-    __shared__ uint32_t red[4][4];
-    a = wave_sum_u32(a); b = wave_sum_u32(b); c = wave_sum_u32(c); d = wave_sum_u32(d);
-    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (lane == 0) { red[wv][0] = a; red[wv][1] = b; red[wv][2] = c; red[wv][3] = d; }
-    __syncthreads();
-    if (threadIdx.x < 4) out[threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-}
-
-__device__ __forceinline__ uint32_t bmin4(uint32_t a, uint32_t b)
-{
-    uint32_t r = 0;
-#pragma unroll
-    for (int k = 0; k < 32; k += 8) { uint32_t x = (a >> k) & 255, y = (b >> k) & 255; r |= (x < y ? x : y) << k; }
-    return r;
-}
-__device__ __forceinline__ uint32_t bmax4(uint32_t a, uint32_t b)
-{
-    uint32_t r = 0;
-#pragma unroll
-    for (int k = 0; k < 32; k += 8) { uint32_t x = (a >> k) & 255, y = (b >> k) & 255; r |= (x > y ? x : y) << k; }
-    return r;
-}
-__device__ __forceinline__ uint32_t babsdiff4(uint32_t a, uint32_t b)
-{
-    uint32_t r = 0;
-#pragma unroll
-    for (int k = 0; k < 32; k += 8) { uint32_t x = (a >> k) & 255, y = (b >> k) & 255; r |= (x > y ? x - y : y - x) << k; }
-    return r;
-}
-// per-dword tail shared by the dense kernels: corr = |img-bg| (already computed), inmask bytes
-// (0xff where mask == 255); accumulates the four sums and returns the 4 threshold bits
-__device__ __forceinline__ uint32_t tail4(uint32_t img, uint32_t corr, uint32_t inm, int thr, uint32_t &s0, uint32_t &s1,
-                                          uint32_t &s2, uint32_t &s3)
-{
-    uint32_t cm = corr & inm, bitsv = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        uint32_t x = (img >> (8 * k)) & 255, c = (cm >> (8 * k)) & 255;
-        s0 += x; s1 += x * x; s2 += c; s3 += c * c;
-        bitsv |= (uint32_t)((int)c > thr) << k;
-    }
-    return bitsv;
-}
-__device__ __forceinline__ uint32_t eq255_4(uint32_t m)
-{
-    uint32_t r = 0;
-#pragma unroll
-    for (int k = 0; k < 32; k += 8) r |= (((m >> k) & 255) == 255 ? 255u : 0u) << k;
-    return r;
-}
-
-// ------------------------------------------------------------------------------------------------
-// dense kernels.  Thread = one 8-pixel strip (uint2); block = 256 threads = 2048 pixels;
-// grid = (ceil(P/2048), frames).  partials[(f*nblk+blk)*4 + {0,1,2,3}] = sum x, sum x^2 (raw frame),
-// sum c, sum c^2 (corrected inside the mask).
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_bg_generic(const uint8_t *__restrict__ frames, int n, int NW, size_t P,
-                                                    uint8_t *__restrict__ cleaned, const uint8_t *__restrict__ mask,
-                                                    int thr, uint8_t *__restrict__ bits8, uint32_t *__restrict__ partials)
-{
-    size_t strip = (size_t)blockIdx.x * 256 + threadIdx.x;
-    int f = blockIdx.y;
-    uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-    if (strip * 8 < P) {
-        int start = (f + NW < n) ? f : n - NW;             // bg_correction.py:72 (may be negative: Python wrap)
-        auto ld = [&](int idx) { if (idx < 0) idx += n; return *(const uint2 *)(frames + (size_t)idx * P + strip * 8); };
-        uint2 prev = ld(start), bg = make_uint2(0, 0);
-        for (int j = 1; j < NW; j++) {                     // :74-78
-            uint2 cur = ld(start + j);
-            bg.x = bmax4(bg.x, bmin4(prev.x, cur.x));
-            bg.y = bmax4(bg.y, bmin4(prev.y, cur.y));
-            prev = cur;
-        }
-        uint2 img = ld(f);
-        uint2 corr = make_uint2(babsdiff4(img.x, bg.x), babsdiff4(img.y, bg.y));   // :80
-        *(uint2 *)(cleaned + (size_t)f * P + strip * 8) = make_uint2(~corr.x, ~corr.y);   // :81 (255-c == ~c)
-        uint2 inm = make_uint2(0xffffffffu, 0xffffffffu);
-        if (mask) { uint2 m = *(const uint2 *)(mask + strip * 8); inm = make_uint2(eq255_4(m.x), eq255_4(m.y)); }
-        uint32_t b = tail4(img.x, corr.x, inm.x, thr, s0, s1, s2, s3) | (tail4(img.y, corr.y, inm.y, thr, s0, s1, s2, s3) << 4);
-        bits8[(size_t)f * (P / 8) + strip] = (uint8_t)b;
-    }
-    block_sum4_store(s0, s1, s2, s3, partials + ((size_t)f * gridDim.x + blockIdx.x) * 4);
-}
-
-// ------------------------------------------------------------------------------------------------
-// streaming background kernel (window of 12 frames = the reference's 2*n_bg_imgs with n_bg_imgs = 6)
-//
-// A thread owns one 8-pixel strip and walks the frames of its time chunk [a, b) in order, so every
-// raw byte is read from HBM once (plus an 11-frame halo per chunk) instead of 12 times.
-//   m[j]   = min(I[j], I[j+1])                          (pair minima, bg_correction.py:76)
-//   bg[s]  = max(m[s] .. m[s+10])                       (bg_correction.py:78) as a trailing sparse table:
-//            T2[j] = max(m[j], m[j-1]); T4[j] = max(T2[j], T2[j-2]); T8[j] = max(T4[j], T4[j-4]);
-//            T11[j] = max(T8[j], T8[j-3]) = max(m[j-10..j]) = bg[j-10]
-//   frame s = j-10 is emitted when frame j+1 arrives; the last 12 frames share bg[n-12] (:72) and are
-//   emitted together when frame n-1 arrives.
-// Pixel values live as u16 pairs (even / odd bytes of a dword) so that v_pk_min/max/sub_u16 apply.
-// All rings are indexed with compile-time phases (loop unrolled by 16); 4 loads stay in flight.
-// No LDS, no barriers: each wave reduces its four sums with DPP and lane 63 stores them.
-// ------------------------------------------------------------------------------------------------
-typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t pkmax(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2_t, a), __builtin_bit_cast(u16x2_t, b))); }
-__device__ __forceinline__ uint32_t pkmin(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2_t, a), __builtin_bit_cast(u16x2_t, b))); }
-__device__ __forceinline__ uint32_t pksub(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, (u16x2_t)(__builtin_bit_cast(u16x2_t, a) - __builtin_bit_cast(u16x2_t, b))); }
-template <int CTRL, int RM> __device__ __forceinline__ uint32_t dpp_add(uint32_t v) { return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, RM, 0xf, false); }
-// sum over the wave, valid in lane 63
-__device__ __forceinline__ uint32_t wave_sum63(uint32_t v)
-{
-    v = dpp_add<0x111, 0xf>(v); v = dpp_add<0x112, 0xf>(v); v = dpp_add<0x114, 0xf>(v); v = dpp_add<0x118, 0xf>(v);
-    v = dpp_add<0x142, 0xa>(v);     // row_bcast:15 into rows 1,3
-    v = dpp_add<0x143, 0xc>(v);     // row_bcast:31 into rows 2,3
-    return v;
-}
-struct Px8 { uint32_t e0, o0, e1, o1; };      // 8 pixels as four registers of two u16 lanes
-__device__ __forceinline__ Px8 px_split(uint2 v)
-{
-    Px8 r;
-    r.e0 = __builtin_amdgcn_perm(0, v.x, 0x0c020c00); r.o0 = __builtin_amdgcn_perm(0, v.x, 0x0c030c01);
-    r.e1 = __builtin_amdgcn_perm(0, v.y, 0x0c020c00); r.o1 = __builtin_amdgcn_perm(0, v.y, 0x0c030c01);
-    return r;
-}
-__device__ __forceinline__ Px8 px_max(Px8 a, Px8 b) { return {pkmax(a.e0, b.e0), pkmax(a.o0, b.o0), pkmax(a.e1, b.e1), pkmax(a.o1, b.o1)}; }
-__device__ __forceinline__ Px8 px_min(Px8 a, Px8 b) { return {pkmin(a.e0, b.e0), pkmin(a.o0, b.o0), pkmin(a.e1, b.e1), pkmin(a.o1, b.o1)}; }
-
-typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
-// A wave-uniform base pointer pinned to scalar registers: the 32-bit lane offset added to it becomes the instruction's
-// offset operand (global_load / global_store with an SGPR base) instead of 64-bit vector arithmetic per access.
-#define PSEG_GLOBAL __attribute__((address_space(1)))
-template <typename T>
-__device__ __forceinline__ T PSEG_GLOBAL *uniform_base(const void *p)
-{
-    const unsigned long long v = (unsigned long long)p;
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
-    return (T PSEG_GLOBAL *)(((unsigned long long)hi << 32) | lo);
-}
-// raw buffer resource over a wave-uniform base: buffer_load / buffer_store take the 32-bit lane offset as it is ("offen"),
-// no vector arithmetic for the address; aux 2 = non-temporal
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t raw_rsrc(const void *base)
-{
-    return __builtin_amdgcn_make_buffer_rsrc((void *)uniform_base<uint8_t>(base), 0, 0x7fffffff, 0x00020000);
-}
-__device__ __forceinline__ uint2 ld_stream_at(const uint8_t *base, uint32_t off)      // base wave-uniform
-{
-    const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(raw_rsrc(base), (int)off, 0, 2);
-    return make_uint2(v.x, v.y);
-}
-__device__ __forceinline__ uint2 ld_stream(const uint8_t *p)
-{
-    u32x2_t v = __builtin_nontemporal_load((const u32x2_t *)p);
-    return make_uint2(v.x, v.y);
-}
-__device__ __forceinline__ uint32_t pkadd(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, (u16x2_t)(__builtin_bit_cast(u16x2_t, a) + __builtin_bit_cast(u16x2_t, b))); }
-struct BgEmit {
-    uint8_t *cleaned, *bits8; uint4 *partials;              // real outputs
-    uint8_t *t_cleaned, *t_bits8; uint4 *t_partials;        // trash rows: where a disabled step stores (keeps the loop branch-free)
-    size_t P; uint32_t off8, strip32; uint2 inm, m80; uint32_t kadd, lowm; uint32_t nwaves, wave;
-    uint32_t act;          // 0xffffffff for strips inside the frame, 0 for the padding lanes of the last wave
-};
-__device__ __forceinline__ uint32_t gather4(uint32_t r)     // bits 7,15,23,31 -> bits 0..3
-{
-    r >>= 7; r |= r >> 7; r |= r >> 14;
-    return r & 0xfu;
-}
-// frame s: cleaned = 255 - |img - bg| (bg_correction.py:80-81), the four sums and the threshold bits
-// (detection.py:178-202).  c = px_split(img).  en is wave-uniform; a disabled call stores into the trash rows.
-// The four sums of the frame are left per lane in (op, os1, os3) -- sum x | sum c << 16, sum x^2, sum c^2 --; bg_flush
-// reduces them over the wave for four frames at a time.
-template <bool PAD>
-__device__ __forceinline__ void bg_emit(const BgEmit &E, uint2 img, Px8 c, Px8 bg, int s, bool en, uint32_t &op, uint32_t &os1, uint32_t &os3)
-{
-    uint32_t de0 = pksub(pkmax(c.e0, bg.e0), pkmin(c.e0, bg.e0)), do0 = pksub(pkmax(c.o0, bg.o0), pkmin(c.o0, bg.o0));
-    uint32_t de1 = pksub(pkmax(c.e1, bg.e1), pkmin(c.e1, bg.e1)), do1 = pksub(pkmax(c.o1, bg.o1), pkmin(c.o1, bg.o1));
-    uint2 corr = make_uint2(__builtin_amdgcn_perm(do0, de0, 0x06020400), __builtin_amdgcn_perm(do1, de1, 0x06020400));
-    // every store is unconditional (disabled steps and padding lanes write to the trash rows): with no
-    // branch in the loop body the compiler counts the outstanding loads exactly (vmcnt counts stores too)
-    const bool real = PAD ? (en && E.act) : en;           // without padding lanes the bases stay wave-uniform (scalar registers)
-    uint8_t *pc = real ? E.cleaned + (size_t)s * E.P : E.t_cleaned;          // wave-uniform bases, 32-bit lane offsets
-    uint8_t *pb = real ? E.bits8 + (size_t)s * (E.P / 8) : E.t_bits8;
-
-    // streamed out: a plain store would leave 1.3 GB of dirty lines to drain from L2 under the kernels that follow
-    {
-        u32x2_t cv; cv.x = ~corr.x; cv.y = ~corr.y;
-        if (PAD) __builtin_nontemporal_store(cv, (u32x2_t *)(pc + E.off8));
-        else __builtin_amdgcn_raw_buffer_store_b64(cv, raw_rsrc(pc), (int)E.off8, 0, 2);
-    }
-    uint2 cm = make_uint2(corr.x & E.inm.x, corr.y & E.inm.y);
-    if (PAD) { img.x &= E.act; img.y &= E.act; }
-    uint32_t s0 = __builtin_amdgcn_sad_u8(img.x, 0u, __builtin_amdgcn_sad_u8(img.y, 0u, 0u));
-    uint32_t s1 = __builtin_amdgcn_udot4(img.x, img.x, __builtin_amdgcn_udot4(img.y, img.y, 0u, false), false);
-    uint32_t s2 = __builtin_amdgcn_sad_u8(cm.x, 0u, __builtin_amdgcn_sad_u8(cm.y, 0u, 0u));
-    uint32_t s3 = __builtin_amdgcn_udot4(cm.x, cm.x, __builtin_amdgcn_udot4(cm.y, cm.y, 0u, false), false);
-    // threshold bits on the packed difference bytes: (d & 0x7f) + (128 - t) carries into bit 7 iff the low seven bits reach
-    // t (t <= 128; together with "d >= 128" by OR) resp. t - 128 (t > 128; AND) -- no carry crosses a byte.  The four flag
-    // bits of a register are gathered by one dot product with the weights 1, 2, 4, 8 (16 .. 128 for the upper register).
-    // OR / AND of the two conditions = majority with a constant third input (all ones: OR, zero: AND), one v_bitop3;
-    // m80 = bit 7 of the bytes inside the mask (0 when no pixel can pass): isolates the flags and applies the mask at once
-    const uint32_t t0 = (corr.x & 0x7f7f7f7fu) + E.kadd, t1 = (corr.y & 0x7f7f7f7fu) + E.kadd;
-    const uint32_t f0 = __builtin_amdgcn_bitop3_b32(t0, corr.x, E.lowm, 0xE8) & E.m80.x, f1 = __builtin_amdgcn_bitop3_b32(t1, corr.y, E.lowm, 0xE8) & E.m80.y;
-    const uint32_t b = __builtin_amdgcn_udot4(f1, 0x80402010u, __builtin_amdgcn_udot4(f0, 0x08040201u, 0u, false), false) >> 7;
-    if (PAD) pb[E.strip32] = (uint8_t)b;
-    else __builtin_amdgcn_raw_buffer_store_b8((uint8_t)b, raw_rsrc(pb), (int)E.strip32, 0, 0);
-    op = s0 | (s2 << 16);                                   // sum x and sum c (<= 2040 per lane) travel packed in one register
-    os1 = s1; os3 = s3;
-}
-// Wave sums of four frames at once.  Two swap levels put frame r into row r of the wave (v_permlane32_swap exchanges the
-// upper half of one register with the lower half of another, v_permlane16_swap the odd rows with the even rows: swap + add
-// halves two registers into one, each lane then holds the sum over the four rows at its position), four row_shr levels sum
-// the 16 lanes of a row: lanes 15 / 31 / 47 / 63 hold the totals of frames s0 .. s0+3 and store them.  30 vector
-// instructions for four frames and three registers instead of 19 per frame.
-// Frame s0 + r is stored for r < cnt and lo <= s0 + r < hi; the others go to the trash rows.
-typedef unsigned int u32pair_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t rows_of_frames(uint32_t f0, uint32_t f1, uint32_t f2, uint32_t f3)
-{
-    const u32pair_t a = __builtin_amdgcn_permlane32_swap(f0, f2, false, false);      // [f0 lo, f2 lo], [f0 hi, f2 hi]
-    const u32pair_t b = __builtin_amdgcn_permlane32_swap(f1, f3, false, false);
-    const uint32_t x = a[0] + a[1], y = b[0] + b[1];        // rows 0,1: f0 (f1); rows 2,3: f2 (f3)
-    const u32pair_t c = __builtin_amdgcn_permlane16_swap(x, y, false, false);         // [x0, y0, x2, y2], [x1, y1, x3, y3]
-    return c[0] + c[1];                                      // row r: frame r, summed over the four rows
-}
-struct BgSums { uint32_t p[4], s1[4], s3[4]; };
-__device__ __forceinline__ void bg_flush(const BgEmit &E, const BgSums &A, int s0, int lo, int hi, int cnt)
-{
-    uint32_t p = rows_of_frames(A.p[0], A.p[1], A.p[2], A.p[3]);
-    uint32_t s1 = rows_of_frames(A.s1[0], A.s1[1], A.s1[2], A.s1[3]);
-    uint32_t s3 = rows_of_frames(A.s3[0], A.s3[1], A.s3[2], A.s3[3]);
-    p = dpp_add<0x111, 0xf>(p); p = dpp_add<0x112, 0xf>(p); p = dpp_add<0x114, 0xf>(p);     // <= 8 * 4 * 2040 per half: no carry yet
-    const uint32_t q = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p, 0x118, 0xf, 0xf, false);
-    s1 = dpp_add<0x111, 0xf>(s1); s1 = dpp_add<0x112, 0xf>(s1); s1 = dpp_add<0x114, 0xf>(s1); s1 = dpp_add<0x118, 0xf>(s1);
-    s3 = dpp_add<0x111, 0xf>(s3); s3 = dpp_add<0x112, 0xf>(s3); s3 = dpp_add<0x114, 0xf>(s3); s3 = dpp_add<0x118, 0xf>(s3);
-    const int lane = threadIdx.x & 63, r = lane >> 4, fr = s0 + r;
-    if ((lane & 15) == 15) {
-        const bool ok = r < cnt && fr >= lo && fr < hi;
-        uint4 *pp = ok ? E.partials + (size_t)fr * E.nwaves : E.t_partials;
-        pp[E.wave] = make_uint4((p & 0xffffu) + (q & 0xffffu), s1, (p >> 16) + (q >> 16), s3);
-    }
-}
-
-// Per-thread state.  The 12-frame history of raw pixels lives in an LDS ring (dynamic slot index,
-// private to the thread: no barriers); the sparse table and 4 prefetched frames live in registers
-// with compile-time phases (loop unrolled by 4).
-struct BgRegs {
-    uint2 pf[4];           // frames k .. k+3 (pf[PH] is the frame of the current step)
-    Px8 prev;              // frame k-1, split
-    Px8 mp, t2[2], t4[4], t8[4], last;
-    BgSums acc;            // per-lane sums of the frames emitted by the last (up to) four steps
-};
-#define BG_SLOTS 16
-template <int PH, bool PAD>
-__device__ __forceinline__ void bg_step(BgRegs &R, uint2 *ring, const BgEmit &E, const uint8_t *__restrict__ src, int k, int a,
-                                        int kend, int n)
-{
-    const uint2 cur = R.pf[PH];
-    int kn = k + 4 <= kend ? k + 4 : kend;                  // clamped prefetch: always a valid frame
-    R.pf[PH] = ld_stream_at(src + (size_t)kn * E.P, E.off8);   // src is wave-uniform
-    ring[(k & (BG_SLOTS - 1)) * 256] = cur;
-    const uint2 old = ring[((k - 11) & (BG_SLOTS - 1)) * 256];   // frame k-11 (zeros during warm-up)
-    const Px8 cs = px_split(cur);
-    Px8 m = px_min(R.prev, cs);                             // pair minimum m[k-1]
-    if (k == a) m = Px8{0, 0, 0, 0};                         // no pair yet at the first frame of the chunk
-    R.prev = cs;
-    Px8 t2 = px_max(m, R.mp); R.mp = m;
-    Px8 t4 = px_max(t2, R.t2[(PH + 1) & 1]); R.t2[(PH + 1) & 1] = t2;
-    Px8 t8 = px_max(t4, R.t4[(PH + 3) & 3]); R.t4[(PH + 3) & 3] = t4;
-    Px8 t11 = px_max(t8, R.t8[PH & 3]); R.t8[(PH + 3) & 3] = t8;
-    R.last = t11;
-    bg_emit<PAD>(E, old, px_split(old), t11, k - 11, k - 11 >= a && k < n - 1, R.acc.p[PH], R.acc.s1[PH], R.acc.s3[PH]);
-}
-
-// grid = (ceil(P/2048), chunks); chunk c emits frames [bounds[c], bounds[c+1]) of the reference batch that ends at frame
-// bounds[chunks + 1 + c] (several batches in one launch: every batch is at least one chunk).  PAD: the last block has lanes
-// beyond the frame (P % 2048 != 0).
-template <bool PAD>
-__global__ __launch_bounds__(256, 4) void k_bg_stream(const uint8_t *__restrict__ frames, size_t P, uint8_t *__restrict__ cleaned,
-                                                      const uint8_t *__restrict__ mask, int thr, uint8_t *__restrict__ bits8,
-                                                      uint4 *__restrict__ partials, const int *__restrict__ bounds,
-                                                      uint8_t *__restrict__ trash, uint32_t *__restrict__ maskpart,
-                                                      int nfull, int tailk)
-{
-    __shared__ uint2 lds[BG_SLOTS * 256];
-    // strips [0, nfull) walk their whole chunk; each strip behind them is shared by tailk blocks, which walk the tail bounds
-    // (stored behind the chunk tables; tailk > 1 only with one chunk) -- see run_bg
-    int col = blockIdx.x, bi = blockIdx.y;
-    if (tailk > 1 && col >= nfull) {
-        const int t = col - nfull;
-        col = nfull + t / tailk;
-        bi = 2 * gridDim.y + 1 + (t - (col - nfull) * tailk);
-    }
-    const int ncols = nfull + (gridDim.x - nfull) / tailk;
-    size_t strip = (size_t)col * 256 + threadIdx.x;
-    const bool act = strip * 8 < P;                         // padding lanes stay in the wave (DPP sums), load strip 0, store nothing
-    if (!act) strip = 0;
-    const int a = bounds[bi], b = bounds[bi + 1];
-    const int n = bounds[gridDim.y + 1 + blockIdx.y];        // end of the reference batch this chunk belongs to
-    const int kend = (b == n) ? n - 1 : b + 10;
-    BgEmit E;
-    E.cleaned = cleaned; E.bits8 = bits8; E.partials = partials; E.P = P;
-    E.strip32 = (uint32_t)strip; E.off8 = (uint32_t)strip * 8u;             // P <= 2^29: lane offsets fit 32 bits
-    E.t_cleaned = trash; E.t_bits8 = trash + P; E.t_partials = (uint4 *)(trash + P + P / 8);
-    E.inm = make_uint2(0xffffffffu, 0xffffffffu);
-    if (mask) { uint2 m = *(const uint2 *)(mask + strip * 8); E.inm = make_uint2(eq255_4(m.x), eq255_4(m.y)); }
-    E.act = act ? 0xffffffffu : 0u;
-    E.inm.x &= E.act; E.inm.y &= E.act;
-    const int t1 = thr + 1 > 0 ? thr + 1 : 0;               // pixel > thr  <=>  pixel >= thr + 1 (negative thr: every pixel)
-    const bool thr_ok = t1 <= 255;                          // thr >= 255: no pixel passes
-    E.kadd = (uint32_t)(t1 <= 128 ? 128 - t1 : 256 - (t1 > 255 ? 255 : t1)) * 0x01010101u;
-    E.lowm = t1 <= 128 ? 0xffffffffu : 0u;
-    E.m80 = thr_ok ? make_uint2(E.inm.x & 0x80808080u, E.inm.y & 0x80808080u) : make_uint2(0u, 0u);
-    E.nwaves = ncols * 4; E.wave = col * 4 + (threadIdx.x >> 6);
-    if (mask && a == 0) {                          // pixels with mask == 255, per wave (summed by k_reduce_partials)
-        const uint32_t mc = wave_sum63((uint32_t)__popc(gather4(E.inm.x & 0x80808080u) | (gather4(E.inm.y & 0x80808080u) << 4)));
-        if ((threadIdx.x & 63) == 63) maskpart[E.wave] = mc;
-    }
-    const uint8_t *src = frames;
-    uint2 *ring = lds + threadIdx.x;
-#pragma unroll
-    for (int q = 0; q < BG_SLOTS; q++) ring[q * 256] = make_uint2(0, 0);
-    BgRegs R;
-    const Px8 z = {0, 0, 0, 0};
-    R.mp = z; R.last = z; R.prev = z;
-    for (int i = 0; i < 2; i++) R.t2[i] = z;
-    for (int i = 0; i < 4; i++) { R.t4[i] = z; R.t8[i] = z; }
-#pragma unroll
-    for (int i = 0; i < 4; i++) R.pf[i] = ld_stream(src + (size_t)(a + i <= kend ? a + i : kend) * P + E.off8);
-    int k = a;
-    for (; k + 3 <= kend; k += 4) {                         // branch-free body: counted waits keep 4 loads in flight
-        bg_step<0, PAD>(R, ring, E, src, k, a, kend, n);
-        bg_step<1, PAD>(R, ring, E, src, k + 1, a, kend, n);
-        bg_step<2, PAD>(R, ring, E, src, k + 2, a, kend, n);
-        bg_step<3, PAD>(R, ring, E, src, k + 3, a, kend, n);
-        bg_flush(E, R.acc, k - 11, a, n - 12, 4);           // (step k emits frame k - 11, stored while a <= k - 11 and k < n - 1)
-    }
-    if (k <= kend) {
-        const int left = kend - k + 1;                      // 1 .. 3 steps
-        bg_step<0, PAD>(R, ring, E, src, k, a, kend, n);
-        if (left > 1) bg_step<1, PAD>(R, ring, E, src, k + 1, a, kend, n);
-        if (left > 2) bg_step<2, PAD>(R, ring, E, src, k + 2, a, kend, n);
-        bg_flush(E, R.acc, k - 11, a, n - 12, left);
-    }
-    if (b == n) {                                           // the last 12 frames share bg[n-12] = T11 of the final step;
-#pragma unroll 1
-        for (int i = n - 12; i < n; i += 4) {                // their raw pixels are still in the ring (a <= n - 12)
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint2 img = ring[((i + j) & (BG_SLOTS - 1)) * 256];
-                bg_emit<PAD>(E, img, px_split(img), R.last, i + j, true, R.acc.p[j], R.acc.s1[j], R.acc.s3[j]);
-            }
-            bg_flush(E, R.acc, i, n - 12, n, 4);
-        }
-    }
-}
-
-// detection.py:178-202 for a cleaned image that did not come from k_bg_* (e.g. after deconvolution)
-__global__ __launch_bounds__(256) void k_threshold(const uint8_t *__restrict__ cleaned, size_t P, const uint8_t *__restrict__ mask,
-                                                   int thr, uint8_t *__restrict__ bits8, uint32_t *__restrict__ partials)
-{
-    size_t strip = (size_t)blockIdx.x * 256 + threadIdx.x;
-    int f = blockIdx.y;
-    uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-    if (strip * 8 < P) {
-        uint2 cl = *(const uint2 *)(cleaned + (size_t)f * P + strip * 8);
-        uint2 corr = make_uint2(~cl.x, ~cl.y);
-        uint2 inm = make_uint2(0xffffffffu, 0xffffffffu);
-        if (mask) { uint2 m = *(const uint2 *)(mask + strip * 8); inm = make_uint2(eq255_4(m.x), eq255_4(m.y)); }
-        uint32_t b = tail4(cl.x, corr.x, inm.x, thr, s0, s1, s2, s3) | (tail4(cl.y, corr.y, inm.y, thr, s0, s1, s2, s3) << 4);
-        bits8[(size_t)f * (P / 8) + strip] = (uint8_t)b;
-    }
-    block_sum4_store(s0, s1, s2, s3, partials + ((size_t)f * gridDim.x + blockIdx.x) * 4);
-}
-
-// per-frame reduction of the block partials; fsums[f*4+k] u64.  If setvalid: valid[f] = std > 2,
-// decided exactly in integers: P*sum(x^2) - sum(x)^2 > 4*P^2   (bg_correction.py:71)
-__global__ __launch_bounds__(1024) void k_reduce_partials(const uint32_t *__restrict__ partials, int nblk, unsigned long long P,
-                                                          unsigned long long *__restrict__ fsums, uint8_t *__restrict__ valid,
-                                                          int setvalid, int first, int count,
-                                                          unsigned long long *__restrict__ cnt_totals, uint32_t *__restrict__ bandmax,
-                                                          const uint32_t *__restrict__ maskpart, int nmaskpart,
-                                                          unsigned long long *__restrict__ scan, int nscan)
-{
-    __shared__ unsigned long long red[16][4];
-    int f = blockIdx.x;
-    // every block clears its share of the look-back scan's state (ticket, error flag, one word per band: k_runs_band)
-    for (int i = f * 1024 + threadIdx.x; i < nscan; i += gridDim.x * 1024) scan[i] = 0;
-    // block 0 also clears the counters of the detection that follows (mask count | 4 totals, largest band) and, when the
-    // background kernel left per-wave counts of mask pixels, sums them
-    if (f == 0 && cnt_totals) {
-        if (threadIdx.x >= 1 && threadIdx.x < 5) cnt_totals[threadIdx.x] = 0;
-        if (threadIdx.x == 5) { bandmax[0] = 0; bandmax[1] = 0; }
-        unsigned long long m = 0;
-        for (int b = threadIdx.x; b < nmaskpart; b += 1024) m += maskpart[b];
-        for (int o = 32; o > 0; o >>= 1) m += __shfl_down(m, o, 64);
-        __shared__ unsigned long long mred[16];
-        if ((threadIdx.x & 63) == 0) mred[threadIdx.x >> 6] = m;
-        __syncthreads();
-        if (threadIdx.x == 0) { unsigned long long t = 0; for (int w = 0; w < 16; w++) t += mred[w]; cnt_totals[0] = t; }
-    }
-    unsigned long long a[4] = {0, 0, 0, 0};
-    const uint4 *p4 = (const uint4 *)partials + (size_t)f * nblk;
-    for (int b = threadIdx.x; b < nblk; b += 1024) {
-        const uint4 v = p4[b];
-        a[0] += v.x; a[1] += v.y; a[2] += v.z; a[3] += v.w;
-    }
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-        for (int o = 32; o > 0; o >>= 1) a[k] += __shfl_down(a[k], o, 64);
-    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (lane == 0) for (int k = 0; k < 4; k++) red[wv][k] = a[k];
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned long long s[4] = {0, 0, 0, 0};
-        for (int w = 0; w < 16; w++) for (int k = 0; k < 4; k++) s[k] += red[w][k];
-        for (int k = first; k < first + count; k++) fsums[(size_t)f * 4 + k] = s[k];
-        // (128-bit: P * sum x^2 reaches 2^64 from frames of 2^24 pixels on)
-        if (setvalid) valid[f] = ((unsigned __int128)P * s[1] - (unsigned __int128)s[0] * s[0]) > (unsigned __int128)4 * P * P;
-    }
-}
-
-__global__ __launch_bounds__(256) void k_mask_count(const uint8_t *__restrict__ mask, size_t P, unsigned long long *cnt)
-{
-    uint32_t c = 0;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i * 8 < P; i += (size_t)gridDim.x * blockDim.x) {
-        uint2 m = *(const uint2 *)(mask + i * 8);
-        c += __popc(eq255_4(m.x) & 0x01010101u) + __popc(eq255_4(m.y) & 0x01010101u);
-    }
-    __shared__ uint32_t red[4];
-    c = wave_sum_u32(c);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
-    __syncthreads();
-    if (threadIdx.x == 0 && (red[0] | red[1] | red[2] | red[3])) atomicAdd(cnt, (unsigned long long)red[0] + red[1] + red[2] + red[3]);
-}
-
-__global__ void k_fill_spans(uint8_t *mask, int H, int W, const int32_t *spans)
-{
-    int y = blockIdx.x;
-    int xa = spans[2 * y], xb = spans[2 * y + 1];
-    for (int x = threadIdx.x; x < W; x += blockDim.x) mask[(size_t)y * W + x] = (x >= xa && x <= xb) ? 255 : 0;
-}
-
-__global__ void k_synth(uint8_t *out, int H, int W, int frame0, unsigned long long seed, const int32_t *objs, const int32_t *foff)
-{
-    int f = blockIdx.y;
-    size_t P = (size_t)H * W;
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P) return;
-    int y = (int)(i / W), x = (int)(i % W);
-    int v = synth_background(x, y, H, W, seed, frame0 + f);
-    for (int k = foff[f]; k < foff[f + 1]; k++) v -= synth_object_hit(objs + 8 * (size_t)k, x, y);
-    out[(size_t)f * P + i] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
-}
-
-// ------------------------------------------------------------------------------------------------
-// sparse kernels: wrappers around pseg_core.h bodies
-// ------------------------------------------------------------------------------------------------
-#define GTID ((size_t)blockIdx.x * blockDim.x + threadIdx.x)
-// inclusive prefix sum over the wave (DPP); lane 63 holds the total
-__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) { return wave_sum63(v); }
-__device__ __forceinline__ uint32_t lane_shr1(uint32_t v)      // value of lane-1, 0 for lane 0 (wave_shr:1)
-{
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false);
-}
-// Foreground runs, one wave per group of RUNS_RPW rows (lane = 64-bit word of the current row; rows longer
-// than 64 words loop with a carry).  FILL = false: rowcnt[row] = number of runs.  FILL = true: write
-// run_x / run_fy from the row's first index; rows without runs are skipped without touching the plane.
-#define RUNS_RPW 16
-template <bool FILL>
-__global__ __launch_bounds__(256) void k_runs(SegState S, int nrows)
-{
-    const int lane = threadIdx.x & 63;
-    // the wave index is uniform: keeping it in a scalar register moves all per-row index arithmetic off the VALU
-    const int row0 = (blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) * RUNS_RPW;
-    if (row0 >= nrows) return;
-    unsigned long long todo;
-    int startv = 0;                                       // lane i < RUNS_RPW: index of the first run of row row0 + i
-    {
-        const int row = row0 + lane;
-        bool want = lane < RUNS_RPW && row < nrows;
-        if (want) {
-            const int f = row / S.H;
-            if (!S.valid[f]) { want = false; if (!FILL) S.rowcnt[row] = 0; }
-            else if (FILL) { want = seg_rowcount(S, f, row - f * S.H) != 0; startv = seg_rowstart(S, f, row - f * S.H); }
-        }
-        todo = __ballot(want);
-    }
-    // rows of up to 64 words: the words of all wanted rows are loaded first (one memory latency per wave)
-    uint64_t pre[RUNS_RPW];
-    const bool small = S.WW <= 64;
-    if (small) {
-#pragma unroll
-        for (int i = 0; i < RUNS_RPW; i++)
-            pre[i] = (((todo >> i) & 1ull) && lane < S.WW) ? S.bits[(size_t)(row0 + i) * S.WW + lane] : 0;
-    }
-#pragma unroll
-    for (int i = 0; i < RUNS_RPW; i++) {
-        if (!((todo >> i) & 1ull)) continue;
-        const int row = row0 + i;
-        const int f = row / S.H, y = row - f * S.H;
-        const uint64_t *rb = S.bits + (size_t)row * S.WW;
-        uint32_t total = 0, carry = 0;
-        const int base = FILL ? __builtin_amdgcn_readlane(startv, i) : 0;
-        for (int w0 = 0; w0 < S.WW; w0 += 64) {
-            const int w = w0 + lane;
-            const uint64_t v = small ? pre[i] : (w < S.WW ? rb[w] : 0);
-            uint32_t top = (uint32_t)(v >> 63);
-            uint32_t prevtop = lane_shr1(top);
-            if (lane == 0) prevtop = carry;
-            uint64_t st = v & ~((v << 1) | prevtop);
-            uint32_t c = (uint32_t)__popcll(st);
-            uint32_t incl = wave_scan_incl(c);
-            if (FILL) {
-                // ones that continue a run from bit 0 of this word on, over the following words of the chunk: suffix
-                // doubling over the lanes (bit 31 = "every word so far is full"); only when some word ends set
-                uint32_t ext = 0;
-                if (__ballot(top != 0)) {
-                    ext = (v == ~0ull) ? (0x80000000u | 64u) : (uint32_t)(__ffsll((unsigned long long)~v) - 1);
-#pragma unroll
-                    for (int d = 1; d < 64; d <<= 1) {
-                        uint32_t o = __shfl_down(ext, d, 64);
-                        if (lane + d > 63) o = (w0 + 64 < S.WW) ? 0x80000000u : 0u;   // beyond the chunk: unknown / row end
-                        if (ext & 0x80000000u) ext = (ext & 0x7fffffffu) + (o & 0x7fffffffu) + (o & 0x80000000u);
-                    }
-                }
-                uint32_t extn = __shfl_down(ext, 1, 64);           // continuation available in the next word
-                if (lane == 63) extn = 0x80000000u;                  // unknown beyond the chunk: read the plane
-                int idx = base + (int)total + (int)(incl - c);
-                while (st) {
-                    int s = __ffsll((unsigned long long)st) - 1;
-                    st &= st - 1;
-                    uint64_t t = ~(v >> s);                       // zeros mark the run's extent from bit s
-                    int ones = t ? __ffsll((unsigned long long)t) - 1 : 64;
-                    int xe = 64 * w + s + ones - 1;
-                    if (s + ones == 64 && w + 1 < S.WW) {           // run continues into the next words
-                        if (!(extn & 0x80000000u)) xe += (int)extn;
-                        else {                                      // reaches the end of the chunk (rows wider than 4096 px) or of the row
-                            int k = w + 1;
-                            if (lane != 63) { xe += (int)(extn & 0x7fffffffu); k = w0 + 64; }
-                            for (; k < S.WW; k++) {
-                                uint64_t u = rb[k];
-                                if (u == ~0ull) { xe += 64; continue; }
-                                xe += __ffsll((unsigned long long)~u) - 1;
-                                break;
-                            }
-                        }
-                    }
-                    S.run_x[idx] = (uint32_t)(64 * w + s) | ((uint32_t)xe << 16);
-                    S.run_fy[idx] = (uint32_t)y | ((uint32_t)f << 16);
-                    idx++;
-                }
-            }
-            total += __builtin_amdgcn_readlane(incl, 63);
-            carry = __builtin_amdgcn_readlane(top, 63);
-        }
-        if (!FILL && lane == 0) S.rowcnt[row] = total;
-    }
-}
-__global__ void k_init(SegState S, int nfg, int nt) { size_t g = GTID; if (g < (size_t)nt) init_body(S, (int)g, nfg); }
-// both union passes in one launch (two independent union-find structures)
-__global__ void k_unions(SegState S, int nfg, int nt, int bandh)
-{
-    size_t g = GTID;
-    if (g < (size_t)nfg) fg_union_body(S, (int)g, bandh);
-    if (g < (size_t)nt) bg_union_body(S, (int)g, nfg, bandh);
-}
-
-#define BAND_H 64
-#define BAND_CAP 1024
-// The kernels of the labelling chain are queued before the host has seen the run count (no host round trip in the middle
-// of a call): they are sized by the capacity of the run tables and do nothing when the runs did not fit (cap) or when a band
-// had too many runs for the LDS labelling (bcap); the host then repeats the chain the slow way.  framebase[F] = runs of the
-// batch, [F + 1] = largest band, [F + 2] = error flag of the look-back scan.
-__device__ __forceinline__ bool chain_ok(const SegState &S, uint32_t cap, uint32_t bcap)
-{
-    return S.framebase[S.F] <= cap && S.framebase[S.F + 1] <= bcap;
-}
-// unions across the band boundaries only: block = the first row of a band (y = BAND_H, 2 BAND_H, ...) of one frame, a
-// thread per run (its foreground unions with the row above, and the gap on its left) plus one for the trailing gap.  The
-// per-element launch (k_unions over all runs and gaps) has one thread in BAND_H with work.
-__global__ __launch_bounds__(64) void k_unions_rows(SegState S, int bandh, uint32_t cap, uint32_t bcap)
-{
-    // (queued behind k_runs_band before the host has seen the totals: nothing to do when the runs did not fit the tables
-    // or a band was too large for the LDS labelling -- the host then takes another path)
-    if (cap == 0 || !chain_ok(S, cap, bcap)) return;
-    const int f = blockIdx.y, y = ((int)blockIdx.x + 1) * bandh;
-    if (y >= S.H) return;
-    const int rs = seg_rowstart(S, f, y), n = seg_rowcount(S, f, y);
-    for (int j = threadIdx.x; j <= n; j += 64) {
-        if (j < n) fg_union_body(S, rs + j);
-        bg_union_elem(S, f, y, j);
-    }
-}
-
-// ---- band-local labelling in LDS ----------------------------------------------------------------------------------
-// Block = one band of BAND_H rows of one frame.  The band's runs and gaps are united with a union-find that lives in
-// LDS (same rules as fg_union_body / bg_union_elem, local indices), flattened, and written to the global parent arrays
-// as global indices; k_unions then only unites across the band boundaries and k_flatten_resolve finishes.  The
-// frame-connected background (smallest background index of the frame, seg_b0) is the virtual node -1 here.  Also does
-// the work of k_init for the band.  Used when no band of the batch has more than BAND_CAP runs (k_scan_rows reports
-// the maximum); otherwise the host takes the global path.
-__device__ __forceinline__ int lds_find(int *par, int a)
-{
-    if (a < 0) return -1;
-    int p = par[a];
-    while (p != a && p >= 0) {
-        int g = par[p];
-        if (g != p) par[a] = g;                              // path halving (g may be the virtual root -1)
-        a = p; p = g;
-    }
-    return p < 0 ? -1 : a;
-}
-__device__ __forceinline__ void lds_union(int *par, int a, int b)
-{
-    for (int guard = 0; guard < (1 << 24); guard++) {
-        a = lds_find(par, a); b = lds_find(par, b);
-        if (a == b) return;
-        const int hi = a > b ? a : b, lo = a > b ? b : a;    // hi >= 0; lo may be the virtual root
-        const int old = atomicMin(&par[hi], lo);
-        if (old == hi) return;
-        a = old; b = lo;
-    }
-}
-__global__ __launch_bounds__(256) void k_band_label(SegState S)
-{
-    __shared__ uint32_t lx[BAND_CAP];                     // run_x of the band's runs
-    __shared__ uint16_t ly[BAND_CAP];                     // band-local row of every run
-    __shared__ int fgp[BAND_CAP], bgp[BAND_CAP + BAND_H];
-    __shared__ int lrow[BAND_H + 1];                      // local index of the first run of every row
-    const int f = blockIdx.y, y0 = blockIdx.x * BAND_H, H = S.H;
-    const int nr = (y0 + BAND_H <= H) ? BAND_H : H - y0;  // rows in this band
-    const uint32_t *ro = S.rowoff + (size_t)f * (H + 1) + y0;
-    const int R0 = (int)ro[0];                            // global index of the band's first run
-    const int nb = (int)(ro[nr] - ro[0]);                 // runs in the band (<= BAND_CAP, checked by the host)
-    const int B0g = seg_b0(S, f), Bb = R0 + f * H + y0;   // global background indices: frame-connected / band base
-    for (int t = threadIdx.x; t <= nr; t += 256) lrow[t] = (int)(ro[t] - ro[0]);
-    __syncthreads();
-    // init (k_init's work for this band)
-    for (int i = threadIdx.x; i < nb; i += 256) {
-        const int r = R0 + i;
-        const int y = (int)(S.run_fy[r] & 0xffffu), yl = y - y0;
-        lx[i] = S.run_x[r]; ly[i] = (uint16_t)yl; fgp[i] = i;
-        const int j = i - lrow[yl];
-        bgp[i + yl] = (j == 0 || y == 0 || y == H - 1) ? -1 : i + yl;
-        S.bg_left[Bb + i + yl] = j == 0 ? -1 : r - 1;
-        S.minx[r] = 0x7fffffff; S.maxx[r] = -1; S.maxy[r] = -1; S.area2[r] = 0;
-    }
-    for (int yl = threadIdx.x; yl < nr; yl += 256) {      // trailing gap of every row
-        const int g = lrow[yl + 1] + yl;
-        bgp[g] = -1;
-        S.bg_left[Bb + g] = lrow[yl + 1] == lrow[yl] ? -1 : R0 + lrow[yl + 1] - 1;
-    }
-    __syncthreads();
-    // unions with the previous row of the band (rows yl >= 1)
-    for (int i = threadIdx.x; i < nb + nr; i += 256) {
-        int yl, j, n;
-        if (i < nb) { yl = ly[i]; j = i - lrow[yl]; n = lrow[yl + 1] - lrow[yl]; }
-        else { yl = i - nb; n = lrow[yl + 1] - lrow[yl]; j = n; }                 // trailing gap of row yl
-        if (yl == 0) continue;
-        const int ps = lrow[yl - 1], pn = lrow[yl] - ps, rs = lrow[yl];
-        if (i < nb && pn > 0) {                              // foreground, 8-connectivity (fg_union_body)
-            const int lo = (int)(lx[i] & 0xffffu) - 1, hi = (int)(lx[i] >> 16) + 1;
-            int a = ps, b = ps + pn;                         // first q with xe_q >= lo
-            while (a < b) { const int m = (a + b) >> 1; if ((int)(lx[m] >> 16) >= lo) b = m; else a = m + 1; }
-            for (int q = a; q < ps + pn && (int)(lx[q] & 0xffffu) <= hi; q++) lds_union(fgp, i, q);
-        }
-        {                                                    // background, 4-connectivity (bg_union_elem)
-            const int ga = j == 0 ? -1 : (int)(lx[rs + j - 1] >> 16) + 1;
-            const int ge = j == n ? S.W : (int)(lx[rs + j] & 0xffffu) - 1;
-            const int g = rs + j + yl, pb = ps + (yl - 1);
-            int lo = 0, hi = pn;                             // first gap of the previous row whose right end >= ga
-            while (lo < hi) { const int m = (lo + hi) >> 1; if ((int)(lx[ps + m] & 0xffffu) >= ga + 1) hi = m; else lo = m + 1; }
-            for (int q = lo; q <= pn; q++) {
-                const int qa = q == 0 ? -1 : (int)(lx[ps + q - 1] >> 16) + 1;
-                if (qa > ge) break;
-                lds_union(bgp, g, pb + q);
-            }
-        }
-    }
-    __syncthreads();
-    // flatten and publish as global indices
-    for (int i = threadIdx.x; i < nb + nr; i += 256) {
-        if (i < nb) S.fg_parent[R0 + i] = R0 + lds_find(fgp, i);
-        const int rt = lds_find(bgp, i);
-        S.bg_parent[Bb + i] = rt < 0 ? B0g : Bb + rt;
-    }
-}
-// ---- run extraction + scan + band labelling in ONE pass over the threshold plane ---------------------------------------
-// Block = one band of BAND_H rows of one frame, wave = 16 rows, four lanes per row: a lane requests its quarter of the
-// row's 64-bit words at once (one memory latency per wave) and walks them in order, so the carry between words stays in
-// the lane; run starts  v & ~(v << 1 | carry)  are rare (one word in fifty).  A DPP scan over the wave (lane order = raster
-// order) and the four wave totals give every lane the band-local index of its first run.
-// The global index needs the number of runs in all bands before this one (frame-major, band-major = raster order): a
-// decoupled look-back scan (Merrill / Garland) over the blocks.  Blocks take a ticket when they start, so every block with
-// a smaller ticket is running or done; a block publishes its total (AGGREGATE) as soon as it has counted, wave 0 sums its
-// predecessors' totals 64 at a time until it meets one that already knows its INCLUSIVE prefix, and publishes its own.
-// The runs are staged in LDS, labelled there (same union-find as k_band_label: 8-connected foreground, 4-connected
-// background, the frame-connected background as the virtual node -1) and leave the block once, with global indices, in
-// coalesced stores -- the plane is read once, and the run tables are not read back.
-// Launched before the host knows the run count, into the buffers as they stand: nothing is written to the run tables
-// beyond `cap` entries (the totals still come out right; the host then grows the buffers and launches again).  A band with
-// more than BAND_CAP runs skips the LDS labelling and writes its runs directly; bandmax tells the host to label globally.
-// scan[0] = ticket counter, scan[2 + t] = state of block t: flag << 62 | value.  All cleared by k_reduce_partials.
-#define SCAN_AGG (1ull << 62)
-#define SCAN_INC (2ull << 62)
-#define SCAN_SPIN_MAX (1 << 22)
-#ifndef LB_K
-#define LB_K 1                        // look-back windows (of 256 predecessor blocks) read per round (4: 0.179 ms against 0.157 ms)
-#endif
-// CAP = runs a band may hold for the LDS labelling: 1024 (15 KB of LDS, 8 blocks per CU) for ordinary frames, BAND_CAP_MID
-// (29 KB, 5 blocks per CU) and BAND_CAP_DENSE (57 KB, 2 blocks per CU) for dense ones -- the host moves to the class a batch's
-// largest band asks for, and back down after 8 batches that would have fitted the smaller one with a third to spare
-#define BAND_CAP_MID 2048
-#define BAND_CAP_DENSE 4096
-#ifdef BAND_PROF
-// -DBAND_PROF: thread 0 of every block adds the time (wall_clock64 ticks of 10 ns) it spent in each phase of k_runs_band;
-// pseg_destroy prints the averages.  Not part of the product build.
-__device__ unsigned long long g_band_prof[16];
-#define BAND_STAMP(k) do { if (threadIdx.x == 0) { const unsigned long long now_ = wall_clock64(); dt_[k] = (uint32_t)(now_ - stamp_); stamp_ = now_; \
-                           if ((k) == 5) for (int q_ = 0; q_ < 6; q_++) atomicAdd(&g_band_prof[q_], (unsigned long long)dt_[q_]); } } while (0)
-#else
-#define BAND_STAMP(k) do { } while (0)
-#endif
-template <int WPL, int CAP>
-__global__ __launch_bounds__(256) void k_runs_band(SegState S, int wpl, uint32_t cap, unsigned long long *__restrict__ scan,
-                                                   uint32_t *__restrict__ bandmax)
-{
-#ifdef BAND_PROF
-    unsigned long long stamp_ = wall_clock64();
-    uint32_t dt_[6] = {0, 0, 0, 0, 0, 0};
-    if (threadIdx.x == 0) atomicAdd(&g_band_prof[15], 1ull);
-#endif
-    __shared__ uint32_t lx[CAP];                          // run_x of the band's runs
-    __shared__ uint16_t ly[CAP];                          // band-local row of every run
-    __shared__ int fgp[CAP], bgp[CAP + BAND_H];
-    __shared__ int lrow[BAND_H + 1];                      // local index of the first run of every row
-    __shared__ uint32_t wtot[4];
-    __shared__ uint32_t s_ticket, s_base;
-    const int H = S.H, nbpf = (H + BAND_H - 1) / BAND_H;
-    if (threadIdx.x == 0) s_ticket = (uint32_t)atomicAdd(&scan[0], 1ull);
-    __syncthreads();
-    BAND_STAMP(0);                                        // ticket
-    const int t = (int)s_ticket;
-    const int f = t / nbpf, band = t - f * nbpf, y0 = band * BAND_H;
-    const int nr = (y0 + BAND_H <= H) ? BAND_H : H - y0;  // rows in this band
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, part = lane & 3;
-    const int yl = wv * 16 + (lane >> 2), y = y0 + yl;
-    const bool inband = yl < nr;
-    const bool want = inband && S.valid[f];
-    const uint64_t *rb = S.bits + ((size_t)f * H + (inband ? y : y0)) * S.WW;
-    const int w0 = part * wpl, nw = want ? (w0 + wpl < S.WW ? wpl : S.WW - w0) : 0;     // nw <= wpl <= WPL (may be <= 0)
-    uint64_t v[WPL];
-#pragma unroll
-    for (int k = 0; k < WPL; k++) v[k] = k < nw ? rb[w0 + k] : 0;
-    const uint64_t before = (w0 > 0 && nw > 0) ? rb[w0 - 1] : 0;
-    uint32_t cnt = 0;
-    {
-        uint64_t prev = before;
-#pragma unroll
-        for (int k = 0; k < WPL; k++) {
-            cnt += (uint32_t)__popcll(v[k] & ~((v[k] << 1) | (prev >> 63)));
-            prev = v[k];
-        }
-    }
-    const uint32_t incl = wave_scan_incl(cnt);            // lane order = (row, quarter) = raster order
-    if (lane == 63) wtot[wv] = incl;
-    __syncthreads();
-    BAND_STAMP(1);                                        // bit plane loaded, runs counted
-    uint32_t wbase = 0;
-    for (int w = 0; w < wv; w++) wbase += wtot[w];
-    const uint32_t nb = wtot[0] + wtot[1] + wtot[2] + wtot[3];
-    if (threadIdx.x == 0) {
-        __hip_atomic_store(&scan[2 + t], (t == 0 ? SCAN_INC : SCAN_AGG) | nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (t == 0) s_base = 0;
-        if (nb > *(volatile uint32_t *)bandmax) atomicMax(bandmax, nb);      // (a stale read only costs a redundant atomic)
-        lrow[BAND_H] = (int)nb;
-    }
-    const uint32_t li = wbase + incl - cnt;               // band-local index of the lane's first run
-    if (part == 0) lrow[yl] = (int)li;
-    const bool fits = nb <= CAP;
-    // the lane's runs: into LDS when the band fits, else straight to memory once the base is known
-    auto emit_runs = [&](auto &&put) {
-        uint64_t prev = before;
-        uint32_t idx = li;
-#pragma unroll
-        for (int k = 0; k < WPL; k++) {
-            const uint64_t vv = v[k];
-            uint64_t st = vv & ~((vv << 1) | (prev >> 63));
-            prev = vv;
-            const int w = w0 + k;
-            while (st) {
-                const int s0 = __ffsll((unsigned long long)st) - 1;
-                st &= st - 1;
-                const uint64_t z = ~(vv >> s0);             // zeros mark the run's extent from bit s0
-                const int ones = z ? __ffsll((unsigned long long)z) - 1 : 64;
-                int xe = 64 * w + s0 + ones - 1;
-                if (s0 + ones == 64)                        // the run goes on into the next words (possibly another lane's)
-                    for (int q = w + 1; q < S.WW; q++) {
-                        const uint64_t u = rb[q];
-                        if (u == ~0ull) { xe += 64; continue; }
-                        xe += __ffsll((unsigned long long)~u) - 1;
-                        break;
-                    }
-                put(idx++, (uint32_t)(64 * w + s0) | ((uint32_t)xe << 16));
-            }
-        }
-    };
-    if (fits && cnt) emit_runs([&](uint32_t i, uint32_t rx) { lx[i] = rx; ly[i] = (uint16_t)yl; });
-    __syncthreads();
-    BAND_STAMP(2);                                        // runs in LDS
-    // global background index of the band's first gap.  That gap (the leading gap of the band's first row) touches the
-    // padding column x = -1, so it stands for the frame-connected background (the virtual node -1) of this band; the
-    // representatives of a frame's bands are united by k_unions_rows across the band boundaries, and the smallest one is
-    // seg_b0(S, f) -- the frame's first background index, which only the block of band 0 could know here
-    if (fits) {
-        // init (k_init's work for this band)
-        for (int i = threadIdx.x; i < (int)nb; i += 256) {
-            const int yy = ly[i], j = i - lrow[yy], ya = y0 + yy;
-            fgp[i] = i;
-            bgp[i + yy] = (j == 0 || ya == 0 || ya == H - 1) ? -1 : i + yy;
-        }
-        for (int yy = threadIdx.x; yy < nr; yy += 256) bgp[lrow[yy + 1] + yy] = -1;      // trailing gap of every row
-        __syncthreads();
-        // unions with the previous row of the band (rows yy >= 1)
-        for (int i = threadIdx.x; i < (int)nb + nr; i += 256) {
-            int yy, j, n;
-            if (i < (int)nb) { yy = ly[i]; j = i - lrow[yy]; n = lrow[yy + 1] - lrow[yy]; }
-            else { yy = i - (int)nb; n = lrow[yy + 1] - lrow[yy]; j = n; }                 // trailing gap of row yy
-            if (yy == 0) continue;
-            const int ps = lrow[yy - 1], pn = lrow[yy] - ps, rs = lrow[yy];
-            if (i < (int)nb && pn > 0) {                         // foreground, 8-connectivity (fg_union_body)
-                const int lo = (int)(lx[i] & 0xffffu) - 1, hi = (int)(lx[i] >> 16) + 1;
-                int a = ps, b = ps + pn;                         // first q with xe_q >= lo
-                while (a < b) { const int m = (a + b) >> 1; if ((int)(lx[m] >> 16) >= lo) b = m; else a = m + 1; }
-                for (int q = a; q < ps + pn && (int)(lx[q] & 0xffffu) <= hi; q++) lds_union(fgp, i, q);
-            }
-            {                                                    // background, 4-connectivity (bg_union_elem)
-                const int ga = j == 0 ? -1 : (int)(lx[rs + j - 1] >> 16) + 1;
-                const int ge = j == n ? S.W : (int)(lx[rs + j] & 0xffffu) - 1;
-                const int g = rs + j + yy, pb = ps + (yy - 1);
-                int lo = 0, hi = pn;                             // first gap of the previous row whose right end >= ga
-                while (lo < hi) { const int m = (lo + hi) >> 1; if ((int)(lx[ps + m] & 0xffffu) >= ga + 1) hi = m; else lo = m + 1; }
-                for (int q = lo; q <= pn; q++) {
-                    const int qa = q == 0 ? -1 : (int)(lx[ps + q - 1] >> 16) + 1;
-                    if (qa > ge) break;
-                    lds_union(bgp, g, pb + q);
-                }
-            }
-        }
-        __syncthreads();
-    }
-    BAND_STAMP(3);                                        // labelled
-    // decoupled look-back, after the labelling (most predecessors know their inclusive prefix by now): the whole block
-    // reads 256 predecessor states per round, every wave sums its 64 up to the nearest inclusive one
-    __shared__ uint32_t lb_sum[4 * LB_K], lb_hit[4 * LB_K];
-    if (t > 0) {
-        uint32_t excl = 0;
-        int pos = t - 1;
-        bool timeout = false;
-        for (;;) {
-            // LB_K windows of 256 predecessors per round, all loads in flight together
-            unsigned long long sv[LB_K];
-#pragma unroll
-            for (int k = 0; k < LB_K; k++) {
-                const int idx = pos - 256 * k - (int)threadIdx.x;
-                sv[k] = idx >= 0 ? __hip_atomic_load(&scan[2 + idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : SCAN_INC;   // before block 0: inclusive prefix 0
-            }
-#pragma unroll
-            for (int k = 0; k < LB_K; k++) {
-                const int idx = pos - 256 * k - (int)threadIdx.x;
-                int spins = 0;
-                while ((sv[k] >> 62) == 0 && ++spins < SCAN_SPIN_MAX) {
-                    __builtin_amdgcn_s_sleep(2);
-                    sv[k] = __hip_atomic_load(&scan[2 + idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                if ((sv[k] >> 62) == 0) { timeout = true; sv[k] = SCAN_INC; }   // never expected; the host reports it
-                const unsigned long long incm = __ballot((sv[k] >> 62) == 2);
-                const int L = incm ? (int)__builtin_ctzll(incm) : 64;
-                const uint32_t part_sum = wave_sum63(lane <= L ? (uint32_t)sv[k] : 0u);
-                if (lane == 63) { lb_sum[4 * k + wv] = part_sum; lb_hit[4 * k + wv] = incm != 0; }
-            }
-            if (timeout) bandmax[1] = 1;
-            __syncthreads();
-            bool hit = false;
-            for (int w = 0; w < 4 * LB_K && !hit; w++) { excl += lb_sum[w]; hit = lb_hit[w] != 0; }
-            __syncthreads();
-            if (hit) break;
-            pos -= 256 * LB_K;
-        }
-        if (threadIdx.x == 0) {
-            s_base = excl;
-            __hip_atomic_store(&scan[2 + t], SCAN_INC | (unsigned long long)(excl + nb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __syncthreads();
-    }
-    BAND_STAMP(4);                                        // look-back
-    const int R0 = (int)s_base;                           // global index of the band's first run
-    // (cap == 0: the tables do not exist yet -- not even the background entries every row owns without any run)
-    const bool room = cap > 0 && (unsigned long long)R0 + nb <= (unsigned long long)cap;
-    // row table (global indices), frame bases, the grand total
-    if (part == 0 && inband) S.rowoff[(size_t)f * (H + 1) + y] = (uint32_t)R0 + li;
-    if (threadIdx.x == 0) {
-        if (band == nbpf - 1) S.rowoff[(size_t)f * (H + 1) + H] = (uint32_t)R0 + nb;
-        if (band == 0) S.framebase[f] = (uint32_t)R0;
-        if (t == nbpf * S.F - 1) S.framebase[S.F] = (uint32_t)R0 + nb;
-    }
-    if (!room) return;
-    if (!fits) {                                          // too many runs for the LDS tables: the host labels globally (k_init, k_unions)
-        const uint32_t fy = (uint32_t)y | ((uint32_t)f << 16);
-        if (cnt) emit_runs([&](uint32_t i, uint32_t rx) { S.run_x[R0 + i] = rx; S.run_fy[R0 + i] = fy; });
-        return;
-    }
-    const int Bb = R0 + f * H + y0;                       // global background index of the band's first gap (see below)
-    // flatten and publish: runs, parents (global indices), the per-object accumulators' start values
-    for (int i = threadIdx.x; i < (int)nb + nr; i += 256) {
-        if (i < (int)nb) {
-            const int r = R0 + i, yy = ly[i], j = i - lrow[yy];
-            S.run_x[r] = lx[i];
-            S.run_fy[r] = (uint32_t)(y0 + yy) | ((uint32_t)f << 16);
-            S.fg_parent[r] = R0 + lds_find(fgp, i);
-            S.bg_left[Bb + i + yy] = j == 0 ? -1 : r - 1;
-            S.minx[r] = 0x7fffffff; S.maxx[r] = -1; S.maxy[r] = -1; S.area2[r] = 0;
-        }
-        const int rt = lds_find(bgp, i);
-        S.bg_parent[Bb + i] = rt < 0 ? Bb : Bb + rt;
-    }
-    for (int yy = threadIdx.x; yy < nr; yy += 256) {        // trailing gap of every row
-        const int g = lrow[yy + 1] + yy;
-        S.bg_left[Bb + g] = lrow[yy + 1] == lrow[yy] ? -1 : R0 + lrow[yy + 1] - 1;
-    }
-    BAND_STAMP(5);                                        // published (stores issued)
-}
-
-// flatten + enclosure tree in one launch: every parent is followed to its root on the fly (the parents other threads
-// flatten meanwhile are only ever replaced by one of their ancestors, so a chain stays a chain to the same root)
-__global__ void k_flatten_resolve(SegState S, uint32_t cap, uint32_t bcap)
-{
-    if (!chain_ok(S, cap, bcap)) return;
-    const int nfg = (int)S.framebase[S.F], nbg = nfg + S.F * S.H;
-    size_t g = GTID;
-    if (g < (size_t)nbg) S.bg_parent[g] = uf_find(S.bg_parent, (int)g);
-    if (g >= (size_t)nfg) return;
-    const int r = (int)g;
-    const int root = uf_find(S.fg_parent, r);
-    int R = root;
-    for (int guard = 0; guard < 65536; guard++) {
-        const int y = (int)(S.run_fy[R] & 0xffffu), f = (int)(S.run_fy[R] >> 16);
-        const int hb = uf_find(S.bg_parent, R + f * S.H + y);   // background around R's raster-first pixel
-        if (hb == seg_b0(S, f)) break;                       // frame-connected: R is external
-        R = uf_find(S.fg_parent, S.bg_left[hb]);             // component that owns the hole
-    }
-    S.fg_parent[r] = root;
-    S.ext[r] = R;
-}
-// bounding boxes: the 256 runs of a block are combined per object in an LDS hash table first, so that
-// only one set of global atomics is issued per (block, object)
-__global__ __launch_bounds__(256) void k_bbox(SegState S, uint32_t cap, uint32_t bcap)
-{
-    __shared__ int keys[512], vminx[512], vmaxx[512], vmaxy[512];
-    if (!chain_ok(S, cap, bcap)) return;
-    const int nfg = (int)S.framebase[S.F];
-    for (int i = threadIdx.x; i < 512; i += 256) { keys[i] = -1; vminx[i] = 0x7fffffff; vmaxx[i] = -1; vmaxy[i] = -1; }
-    __syncthreads();
-    size_t g = GTID;
-    if (g < (size_t)nfg) {
-        int r = (int)g, E = S.ext[r];
-        unsigned h = ((unsigned)E * 2654435761u) >> 23;       // 9 bits
-        for (;;) {
-            int old = atomicCAS(&keys[h], -1, E);
-            if (old == -1 || old == E) break;
-            h = (h + 1) & 511;
-        }
-        atomicMin(&vminx[h], run_xs(S, r));
-        atomicMax(&vmaxx[h], run_xe(S, r));
-        const int y = (int)(S.run_fy[r] & 0xffffu), f = (int)(S.run_fy[r] >> 16);
-        atomicMax(&vmaxy[h], y);
-        // object that fills the gap on the left of this run (-1: none, or the row's leading gap)
-        S.gapl[r] = (r == seg_rowstart(S, f, y)) ? -1 : bg_gid(S, f, r + f * S.H + y);
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < 512; i += 256)
-        if (keys[i] >= 0) bbox_flush(S, keys[i], vminx[i], vmaxx[i], vmaxy[i]);
-}
-// contour areas: the contributions of a block's 256 runs are summed per object in an LDS hash table first (a large
-// object receives one contribution per row and span: hundreds of atomics on one word otherwise)
-__global__ __launch_bounds__(256) void k_area(SegState S, uint32_t cap, uint32_t bcap)
-{
-    __shared__ int keys[512], vsum[512];
-    if (!chain_ok(S, cap, bcap)) return;
-    const int nfg = (int)S.framebase[S.F];
-    for (int i = threadIdx.x; i < 512; i += 256) { keys[i] = -1; vsum[i] = 0; }
-    __syncthreads();
-    size_t g = GTID;
-    if (g < (size_t)nfg) {
-        int E;
-        const int add = area_contrib(S, (int)g, &E);
-        if (add) {
-            unsigned h = ((unsigned)E * 2654435761u) >> 23;   // 9 bits
-            for (;;) {
-                int old = atomicCAS(&keys[h], -1, E);
-                if (old == -1 || old == E) break;
-                h = (h + 1) & 511;
-            }
-            atomicAdd(&vsum[h], add);
-        }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < 512; i += 256)
-        if (keys[i] >= 0) atomicAdd(&S.area2[keys[i]], vsum[i]);
-}
-
-// exclusive scan of rowcnt inside each frame (block per frame); ftot[f] = runs in frame f
-__global__ __launch_bounds__(256) void k_scan_rows(SegState S, uint32_t *ftot, uint32_t *bandmax)
-{
-    __shared__ uint32_t wtot[4];
-    __shared__ uint32_t carry;
-    const int f = blockIdx.x, H = S.H, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (int base = 0; base < H; base += 256) {
-        const int y = base + threadIdx.x;
-        const uint32_t v = y < H ? S.rowcnt[(size_t)f * H + y] : 0;
-        uint32_t incl = v;                                   // inclusive scan inside the wave, then across the four waves
-        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
-        if (lane == 63) wtot[wv] = incl;
-        __syncthreads();
-        uint32_t pre = carry;
-        for (int w = 0; w < wv; w++) pre += wtot[w];
-        if (y < H) S.rowoff[(size_t)f * (H + 1) + y] = pre + incl - v;
-        __syncthreads();
-        if (threadIdx.x == 255) carry = pre + incl;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) { S.rowoff[(size_t)f * (H + 1) + H] = carry; ftot[f] = carry; }
-    // largest number of runs in one band of BAND_H rows (decides between k_band_label and the global path)
-    __syncthreads();
-    uint32_t bm = 0;
-    for (int b = threadIdx.x; b * BAND_H < H; b += 256) {
-        const int ya = b * BAND_H, yb = ya + BAND_H < H ? ya + BAND_H : H;
-        const uint32_t c = S.rowoff[(size_t)f * (H + 1) + yb] - S.rowoff[(size_t)f * (H + 1) + ya];
-        bm = c > bm ? c : bm;
-    }
-    for (int o = 32; o > 0; o >>= 1) { uint32_t t = __shfl_xor(bm, o, 64); bm = t > bm ? t : bm; }
-    if (lane == 0) wtot[wv] = bm;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < 4; w++) bm = wtot[w] > bm ? wtot[w] : bm;
-        if (bm > *(volatile uint32_t *)bandmax) atomicMax(bandmax, bm);      // (a stale read only costs a redundant atomic)
-    }
-}
-
-// two-pass path (k_runs): the row table becomes global run indices, like the one k_runs_band writes
-__global__ void k_rowoff_global(SegState S)
-{
-    size_t g = GTID;
-    if (g >= (size_t)S.F * (S.H + 1)) return;
-    S.rowoff[g] += S.framebase[g / (S.H + 1)];
-}
-
-// exclusive scan over the frames by one block: out[0..F] (strided input / output)
-__global__ __launch_bounds__(256) void k_scan_small(const uint32_t *in, uint32_t *out, int F, int stride_in, int stride_out)
-{
-    in += blockIdx.x; out += (size_t)blockIdx.x * (F + 1);  // grid.x > 1: columns in, in+1, .. -> tables out, out + (F+1), ..
-    __shared__ uint32_t sh[256];
-    __shared__ uint32_t carry;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (int base = 0; base < F; base += 256) {
-        int f = base + threadIdx.x;
-        uint32_t v = f < F ? in[(size_t)f * stride_in] : 0;
-        sh[threadIdx.x] = v;
-        __syncthreads();
-        for (int o = 1; o < 256; o <<= 1) {
-            uint32_t t = threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
-            __syncthreads();
-            sh[threadIdx.x] += t;
-            __syncthreads();
-        }
-        uint32_t c0 = carry;
-        if (f < F) out[(size_t)f * stride_out] = c0 + sh[threadIdx.x] - v;
-        __syncthreads();
-        if (threadIdx.x == 255) carry = c0 + sh[255];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) out[(size_t)F * stride_out] = carry;
-}
-
-// ranks of external roots / kept / saved objects inside each frame (block per frame; a thread takes RANK_IPT consecutive
-// runs per round, the three counts of a thread travel through the wave scan packed in one register).
-// ftot3[f*3+{0,1,2}] = number of external contours, kept, saved.
-#define RANK_IPT 4
-__global__ __launch_bounds__(1024) void k_rank(SegState S, double min_seg, double min_save, uint32_t *ftot3, uint32_t cap, uint32_t bcap)
-{
-    __shared__ uint32_t wtot[16];                         // per wave: the three totals, 10 bits each (<= 64 * RANK_IPT)
-    __shared__ uint32_t carry[3];
-    if (!chain_ok(S, cap, bcap)) return;
-    const int f = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int r0 = (int)S.framebase[f], r1 = (int)S.framebase[f + 1];
-    if (threadIdx.x < 3) carry[threadIdx.x] = 0;
-    __syncthreads();
-    for (int base = r0; base < r1; base += 1024 * RANK_IPT) {
-        const int r = base + RANK_IPT * (int)threadIdx.x;
-        const bool full = r + RANK_IPT <= r1;
-        int fp[RANK_IPT], ex[RANK_IPT];
-        if (full) { __builtin_memcpy(fp, S.fg_parent + r, 4 * RANK_IPT); __builtin_memcpy(ex, S.ext + r, 4 * RANK_IPT); }
-        else
-#pragma unroll
-            for (int j = 0; j < RANK_IPT; j++) { fp[j] = r + j < r1 ? S.fg_parent[r + j] : -1; ex[j] = r + j < r1 ? S.ext[r + j] : -1; }
-        uint32_t m0 = 0, m1 = 0, m2 = 0;                    // bit j: run r + j is an external root / kept / saved
-#pragma unroll
-        for (int j = 0; j < RANK_IPT; j++)
-            if (fp[j] == r + j && ex[j] == r + j) {         // is_ext_root
-                const double area = 0.5 * (double)S.area2[r + j];
-                const bool v1 = !(area < min_seg);          // detection.py:223 ("< -> continue")
-                m0 |= 1u << j; m1 |= (uint32_t)v1 << j; m2 |= (uint32_t)(v1 && area > min_save) << j;   // detection.py:235
-            }
-        const uint32_t packed = (uint32_t)__popc(m0) | ((uint32_t)__popc(m1) << 10) | ((uint32_t)__popc(m2) << 20);
-        const uint32_t incl = wave_scan_incl(packed);
-        if (lane == 63) wtot[wv] = incl;
-        __syncthreads();
-        uint32_t p0 = carry[0], p1 = carry[1], p2 = carry[2];
-        for (int w = 0; w < wv; w++) { const uint32_t t = wtot[w]; p0 += t & 0x3ffu; p1 += (t >> 10) & 0x3ffu; p2 += t >> 20; }
-        const uint32_t excl = incl - packed;
-        int o0[RANK_IPT], o1[RANK_IPT], o2[RANK_IPT];
-#pragma unroll
-        for (int j = 0; j < RANK_IPT; j++) {
-            const uint32_t below = (1u << j) - 1u;
-            o0[j] = (int)(p0 + (excl & 0x3ffu) + (uint32_t)__popc(m0 & below));
-            o1[j] = (int)(p1 + ((excl >> 10) & 0x3ffu) + (uint32_t)__popc(m1 & below));
-            o2[j] = (int)(p2 + (excl >> 20) + (uint32_t)__popc(m2 & below));
-        }
-        if (full) {
-            __builtin_memcpy(S.extrank + r, o0, 4 * RANK_IPT); __builtin_memcpy(S.keptrank + r, o1, 4 * RANK_IPT);
-            __builtin_memcpy(S.savedrank + r, o2, 4 * RANK_IPT);
-        } else
-#pragma unroll
-            for (int j = 0; j < RANK_IPT; j++)
-                if (r + j < r1) { S.extrank[r + j] = o0[j]; S.keptrank[r + j] = o1[j]; S.savedrank[r + j] = o2[j]; }
-        __syncthreads();
-        if (threadIdx.x == 1023) {
-            const uint32_t t = wtot[15];
-            carry[0] = p0 + (t & 0x3ffu); carry[1] = p1 + ((t >> 10) & 0x3ffu); carry[2] = p2 + (t >> 20);
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x < 3) ftot3[f * 3 + threadIdx.x] = carry[threadIdx.x];
-}
-
-#ifndef CROP_BAND
-#define CROP_BAND 32768                // (8192 / 16384 / 65536 px: 1.93 / 1.91 / 1.92 ms per step against 1.90 ms)
-#endif
-#ifndef CROP_THREADS
-#define CROP_THREADS 256
-#endif
-#ifndef CROP_UNROLL
-#define CROP_UNROLL 4
-#endif
-#ifndef CROP_TPR
-#define CROP_TPR 4                   // threads that share the runs of one row while the mask is painted (64 rows at a time;
-                                     // 16 / 8 / 2 threads per row: 0.384 / 0.351 / 0.338 ms for the crop group against 0.334 ms)
-#endif
-#ifndef CROP_LDS_WORDS
-#define CROP_LDS_WORDS 2048          // mask words of a band + 2 halo rows on each side (frames up to 8192 px wide: 8 rows of 256 words)
-#endif
-__host__ __device__ inline int crop_rows_per_band(int w)
-{
-    int r = CROP_BAND / w;
-    // (the band-local 32-bit sums of k_crops_sums: sum yl^2 over a full band < w r^3 / 3 < 2^32 for every w with r <= 600,
-    // and r = CROP_BAND / w <= 585 where w >= 56)
-    if (r > 600) r = 600;
-    const int fit = CROP_LDS_WORDS / ((w + 31) >> 5) - 4;  // rows + 4 halo rows of (w + 31) / 32 words fit the LDS arrays
-    if (r > fit) r = fit;
-    return r < 1 ? 1 : r;
-}
-// one row per kept object, ordered (frame, c); c counts from the LAST external root (detection.py:222)
-__global__ void k_emit(SegState S, uint32_t cap, uint32_t bcap, double min_seg, double min_save, const uint32_t *ftot3,
-                       const uint32_t *rowbase, const uint32_t *savedbase, RowsDev R, int32_t *objlabel, int32_t *objflag,
-                       int32_t *saved_row, int32_t *runlabel, int32_t *geo, unsigned long long *sz, size_t szstride)
-{
-    if (!chain_ok(S, cap, bcap)) return;
-    const int nfg = (int)S.framebase[S.F];
-    size_t g = GTID;
-    if (g >= (size_t)nfg) return;
-    int r = (int)g;
-    objflag[r] = 0;
-    objlabel[r] = 0;
-    int f = (int)(S.run_fy[r] >> 16);
-    {   // label-map value of this run: the label of its external component, 0 for components nested in holes
-        const int E = S.ext[r];
-        runlabel[r] = (S.fg_parent[r] == E) ? (int)ftot3[f * 3] - S.extrank[E] : 0;
-    }
-    if (!is_ext_root(S, r)) return;
-    int next = (int)ftot3[f * 3], nkept = (int)ftot3[f * 3 + 1], nsaved = (int)ftot3[f * 3 + 2];
-    int label = next - S.extrank[r];
-    objlabel[r] = label;
-    double area = 0.5 * (double)S.area2[r];
-    if (area < min_seg) return;
-    bool saved = area > min_save;
-    int c = nkept - 1 - S.keptrank[r];
-    int i = (int)rowbase[f] + c;
-    R.frame[i] = f; R.c[i] = c; R.label[i] = label; R.area2[i] = S.area2[r];
-    const int y0 = (int)(S.run_fy[r] & 0xffffu);           // the root run lies in the object's first row
-    const int x = S.minx[r], w = S.maxx[r] - x + 1, h = S.maxy[r] - y0 + 1;
-    R.x[i] = x; R.y[i] = y0;
-    R.w[i] = w; R.h[i] = h;
-    R.saved[i] = saved; R.root[i] = r;
-    objflag[r] = 1 | (saved ? 2 : 0);
-    if (saved) {
-        // geometry of saved object s: geo[s*8] = f, x, y, w, h, root, words-per-row, row; the three size columns
-        // sz[k * szstride + s] = crop bytes | rows (offset of the per-row extremes) | row bands (a band = a run of rows of
-        // about CROP_BAND pixels: the unit of work of k_crops_sums), scanned by k_scan_sizes
-        const size_t sidx = (size_t)savedbase[f] + (size_t)(nsaved - 1 - S.savedrank[r]);
-        saved_row[sidx] = i;
-        int32_t *o = geo + 8 * sidx;
-        o[0] = f; o[1] = x; o[2] = y0; o[3] = w; o[4] = h; o[5] = r; o[6] = (w + 31) >> 5; o[7] = i;
-        const int rpb = crop_rows_per_band(w);
-        sz[sidx] = (unsigned long long)w * h;
-        sz[szstride + sidx] = (unsigned long long)h;
-        sz[2 * szstride + sidx] = (unsigned long long)((h + rpb - 1) / rpb);
-    }
-}
-
-// label map: one dense pass writes every int32 exactly once.  Wave = one 256-pixel span of a row
-// (lane = 4 pixels = one 16-byte store; a block writes 4 consecutive spans, blocks sweep the map in address order --
-// the shape that streams at 6.8 TB/s when it only stores).  A span whose threshold bits are all zero is stored at once.
-// Otherwise the wave works together: the row's runs and their labels are loaded one per lane, the runs that meet the
-// span are broadcast one after the other (typically one or two) and every lane takes what falls on its pixels.
-typedef int32_t i32x4_t __attribute__((ext_vector_type(4)));
-#define FILL_ROWS_MIN 8
-// grid = (ceil(W / 1024), H, frames): row and frame come from the block index (no divisions; at one KiB per wave the
-// kernel only streams at full rate while a wave spends a few dozen instructions)
-__global__ __launch_bounds__(256) void k_label_fill(SegState S, const int32_t *__restrict__ runlabel, int32_t *__restrict__ labels,
-                                                    uint32_t cap, uint32_t bcap)
-{
-    if (!chain_ok(S, cap, bcap)) return;                    // (queued with the chain: see chain_ok)
-    const int lane = threadIdx.x & 63;
-    const int f = blockIdx.z, y = blockIdx.y;
-    const int x0 = blockIdx.x * 1024 + (threadIdx.x >> 6) * 256, x = x0 + 4 * lane;
-    if (x0 >= S.W) return;                                   // wave beyond the row end
-    const bool in = x < S.W;
-    const size_t rowpix = ((size_t)f * S.H + y) * S.W;
-    i32x4_t out = {0, 0, 0, 0};
-    // the row's run list (L2-resident tables) decides, not the threshold plane: a read stream next to the write stream
-    // costs the stores more than the lookups do
-    const int rs = seg_rowstart(S, f, y), n = seg_rowcount(S, f, y);
-    {
-        for (int j0 = 0; j0 < n; j0 += 64) {
-            uint32_t rx = 0xffffu; int lab = 0;              // lanes past the row's runs: xs = 65535, xe = 0
-            if (j0 + lane < n) { rx = S.run_x[rs + j0 + lane]; lab = runlabel[rs + j0 + lane]; }
-            const int xs = (int)(rx & 0xffffu), xe = (int)(rx >> 16);
-            unsigned long long hit = __ballot(lab != 0 && xe >= x0 && xs <= x0 + 255);
-            while (hit) {
-                const int l = __builtin_ctzll(hit);
-                hit &= hit - 1;
-                const int a = __builtin_amdgcn_readlane(xs, l), b = __builtin_amdgcn_readlane(xe, l), lb = __builtin_amdgcn_readlane(lab, l);
-                if (a <= x && x <= b) out.x = lb;
-                if (a <= x + 1 && x + 1 <= b) out.y = lb;
-                if (a <= x + 2 && x + 2 <= b) out.z = lb;
-                if (a <= x + 3 && x + 3 <= b) out.w = lb;
-            }
-            if (__builtin_amdgcn_readlane(xs, 63) > x0 + 255) break;    // runs are sorted: nothing further meets the span
-        }
-    }
-    if (in) __builtin_nontemporal_store(out, (i32x4_t *)(labels + rowpix + x));
-}
-
-// The same map with one wave per ROW (block = 4 consecutive rows): the row's first 64 runs and their labels are loaded
-// once and kept in registers while the wave walks the row's 256-pixel spans, so that a wave's two dependent table loads
-// are paid once per row (10 KiB at W = 2560) instead of once per KiB.  For rows with many runs (dense frames).
-__global__ __launch_bounds__(256) void k_label_fill_rows(SegState S, const int32_t *__restrict__ runlabel, int32_t *__restrict__ labels,
-                                                         uint32_t cap, uint32_t bcap)
-{
-    if (!chain_ok(S, cap, bcap)) return;
-    const int lane = threadIdx.x & 63;
-    const int f = blockIdx.z, y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (y >= S.H) return;
-    const size_t rowpix = ((size_t)f * S.H + y) * S.W;
-    const int rs = seg_rowstart(S, f, y), n = seg_rowcount(S, f, y);
-    uint32_t rx0 = 0xffffu; int lab0 = 0;                    // lanes past the row's runs: xs = 65535, xe = 0
-    if (lane < n) { rx0 = S.run_x[rs + lane]; lab0 = runlabel[rs + lane]; }
-    const int xs0 = (int)(rx0 & 0xffffu), xe0 = (int)(rx0 >> 16);
-    for (int x0 = 0; x0 < S.W; x0 += 256) {
-        const int x = x0 + 4 * lane;
-        i32x4_t out = {0, 0, 0, 0};
-        unsigned long long hit = __ballot(lab0 != 0 && xe0 >= x0 && xs0 <= x0 + 255);
-        while (hit) {
-            const int l = __builtin_ctzll(hit);
-            hit &= hit - 1;
-            const int a = __builtin_amdgcn_readlane(xs0, l), b = __builtin_amdgcn_readlane(xe0, l), lb = __builtin_amdgcn_readlane(lab0, l);
-            if (a <= x && x <= b) out.x = lb;
-            if (a <= x + 1 && x + 1 <= b) out.y = lb;
-            if (a <= x + 2 && x + 2 <= b) out.z = lb;
-            if (a <= x + 3 && x + 3 <= b) out.w = lb;
-        }
-        if (n > 64 && __builtin_amdgcn_readlane(xs0, 63) <= x0 + 255) {       // (runs are sorted) the later batches, from memory
-            for (int j0 = 64; j0 < n; j0 += 64) {
-                uint32_t rx = 0xffffu; int lab = 0;
-                if (j0 + lane < n) { rx = S.run_x[rs + j0 + lane]; lab = runlabel[rs + j0 + lane]; }
-                const int xs = (int)(rx & 0xffffu), xe = (int)(rx >> 16);
-                hit = __ballot(lab != 0 && xe >= x0 && xs <= x0 + 255);
-                while (hit) {
-                    const int l = __builtin_ctzll(hit);
-                    hit &= hit - 1;
-                    const int a = __builtin_amdgcn_readlane(xs, l), b = __builtin_amdgcn_readlane(xe, l), lb = __builtin_amdgcn_readlane(lab, l);
-                    if (a <= x && x <= b) out.x = lb;
-                    if (a <= x + 1 && x + 1 <= b) out.y = lb;
-                    if (a <= x + 2 && x + 2 <= b) out.z = lb;
-                    if (a <= x + 3 && x + 3 <= b) out.w = lb;
-                }
-                if (__builtin_amdgcn_readlane(xs, 63) > x0 + 255) break;
-            }
-        }
-        if (x < S.W) __builtin_nontemporal_store(out, (i32x4_t *)(labels + rowpix + x));
-    }
-}
-
-// exclusive scans of the three size columns by one block of 1024 threads; out[k][0..n].  A thread takes 8 consecutive
-// objects (one pass of wave / block scans per 8192 objects), read and written as 16-byte vectors: the columns are
-// stored one after the other (stride `szstride`, even, with 8 entries of slack behind each column)
-#define SCAN_IPT 8
-typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
-__global__ __launch_bounds__(1024) void k_scan_sizes(SegState S, uint32_t cap, uint32_t bcap, const unsigned long long *sz, size_t szstride,
-                                                      const uint32_t *n_p, long long *crop_off, long long *bits_off,
-                                                      long long *band_off, long long *totals)
-{
-    __shared__ unsigned long long wtot[16][3];
-    __shared__ unsigned long long carry[3];
-    // totals[4..6]: runs of the batch, largest band, scan error flag -- what the host needs to accept or repeat the chain
-    if (threadIdx.x < 3) totals[4 + threadIdx.x] = (long long)S.framebase[S.F + threadIdx.x];
-    if (!chain_ok(S, cap, bcap)) { if (threadIdx.x < 4) totals[threadIdx.x] = 0; return; }
-    const int n = (int)*n_p, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (threadIdx.x < 3) carry[threadIdx.x] = 0;
-    __syncthreads();
-    long long *outp[3] = {crop_off, bits_off, band_off};
-    unsigned long long hmax = 0;                             // tallest saved object (LDS size of k_convex): totals[3]
-    for (int base = 0; base < n; base += 1024 * SCAN_IPT) {
-        const int i0 = base + threadIdx.x * SCAN_IPT;
-        unsigned long long v[3][SCAN_IPT], tot[3] = {0, 0, 0}, inc[3];
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            if (i0 < n) {
-                const u64x2_t *p = (const u64x2_t *)(sz + k * szstride + i0);
-#pragma unroll
-                for (int q = 0; q < SCAN_IPT / 2; q++) { const u64x2_t t = p[q]; v[k][2 * q] = t.x; v[k][2 * q + 1] = t.y; }
-            }
-#pragma unroll
-            for (int j = 0; j < SCAN_IPT; j++) { if (i0 + j >= n) v[k][j] = 0; tot[k] += v[k][j]; }
-        }
-#pragma unroll
-        for (int j = 0; j < SCAN_IPT; j++) hmax = v[1][j] > hmax ? v[1][j] : hmax;   // column 1 = rows of the object
-        for (int k = 0; k < 3; k++) {                        // inclusive scan of the thread totals inside the wave
-            unsigned long long x = tot[k];
-            for (int o = 1; o < 64; o <<= 1) { unsigned long long t = __shfl_up(x, o, 64); if (lane >= o) x += t; }
-            inc[k] = x;
-        }
-        if (lane == 63) for (int k = 0; k < 3; k++) wtot[wv][k] = inc[k];
-        __syncthreads();
-        unsigned long long pre[3] = {carry[0], carry[1], carry[2]};
-        for (int w = 0; w < wv; w++) for (int k = 0; k < 3; k++) pre[k] += wtot[w][k];
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            unsigned long long run = pre[k] + inc[k] - tot[k];
-            if (i0 + SCAN_IPT <= n) {
-                u64x2_t *o = (u64x2_t *)(outp[k] + i0);
-#pragma unroll
-                for (int q = 0; q < SCAN_IPT / 2; q++) {
-                    u64x2_t t; t.x = run; run += v[k][2 * q]; t.y = run; run += v[k][2 * q + 1];
-                    o[q] = t;
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < SCAN_IPT; j++) { if (i0 + j < n) outp[k][i0 + j] = (long long)run; run += v[k][j]; }
-            }
-        }
-        __syncthreads();
-        if (threadIdx.x == 1023) for (int k = 0; k < 3; k++) carry[k] = pre[k] + inc[k];
-        __syncthreads();
-    }
-    if (threadIdx.x < 3) { outp[threadIdx.x][n] = (long long)carry[threadIdx.x]; totals[threadIdx.x] = (long long)carry[threadIdx.x]; }
-    for (int o = 32; o > 0; o >>= 1) { const unsigned long long t = __shfl_xor(hmax, o, 64); hmax = t > hmax ? t : hmax; }
-    __syncthreads();
-    if (lane == 0) wtot[wv][0] = hmax;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < 16; w++) hmax = wtot[w][0] > hmax ? wtot[w][0] : hmax;
-        totals[3] = (long long)hmax;
-    }
-}
-
-// band -> saved object (one wave per object): every band gets a 64-byte descriptor -- the object's geometry, its index, the
-// band's first row, the object's offsets into the crop planes and the row-extremes table -- so that a band's block starts
-// with ONE (scalar) load instead of the chain band -> object -> geometry / offsets.
-//   desc[0..7] = f, x, y, w, h, root, words per row, object ; [8] = first row ; [10..11] = crop offset ; [12..13] = row offset
-#define BAND_DESC_INTS 16
-__global__ __launch_bounds__(256) void k_band_map(int n_saved, const long long *__restrict__ band_off, const int32_t *__restrict__ geo,
-                                                  const long long *__restrict__ crop_off, const long long *__restrict__ row_off,
-                                                  int32_t *__restrict__ band_desc, long long *__restrict__ sums)
-{
-    const int s = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (s >= n_saved) return;
-    if (lane < PSEG_NSUMS) sums[(size_t)s * PSEG_NSUMS + lane] = lane == 6 ? 255 : 0;   // min intensity starts at 255
-    const int4 g0 = *(const int4 *)(geo + 8 * (size_t)s), g1 = *(const int4 *)(geo + 8 * (size_t)s + 4);
-    const long long b0 = band_off[s], b1 = band_off[s + 1], co = crop_off[s], ro = row_off[s];
-    const int rpb = crop_rows_per_band(g0.w);
-    for (long long b = b0 + lane; b < b1; b += 64) {
-        int4 *d = (int4 *)(band_desc + BAND_DESC_INTS * (size_t)b);
-        d[0] = g0;
-        d[1] = make_int4(g1.x, g1.y, g1.z, s);
-        d[2] = make_int4((int)(b - b0) * rpb, 0, (int)(uint32_t)co, (int)(co >> 32));
-        d[3] = make_int4((int)(uint32_t)ro, (int)(ro >> 32), 0, 0);
-    }
-}
-
-__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
-{
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    return v;
-}
-
-// Three crops + integer sums of one row band of a saved object (block per band; bands of ~4096 px keep
-// every block short, large objects are spread over many CUs).
-//  phase 1: the band's cumulative filled mask as bits in LDS, one thread per 32-pixel word: a pixel is set iff
-//           it lies in the hole-filled region of a SAVED object iterated at or before this one (root index >=
-//           own root) -- detection.py:206,245-246, the frame mask accumulates over the object loop;
-//  phase 2: crops (detection.py:243-247) and the sums, combined across bands with integer atomics (exact).
-// sums[s*PSEG_NSUMS + k]: 0 N, 1 sum r, 2 sum c, 3 sum r^2, 4 sum c^2, 5 sum r*c, 6 min I, 7 max I, 8 sum I,
-//   9 filled area, 10..12 perimeter code counts (weight 1, sqrt2, (1+sqrt2)/2), 13 euler, 14 convex area
-// p / d and p % d for small non-negative p (< 2^22) with the reciprocal in single precision and one correction step: the
-// integer division of the compiler is some 25 instructions, several of them quarter-rate 32-bit multiplies
-__device__ __forceinline__ void divmod_small(int p, int d, float rcp, int &q, int &r)
-{
-    q = (int)((float)p * rcp);
-    r = p - (int)__umul24((uint32_t)q, (uint32_t)d);
-    if (r < 0) { q--; r += d; } else if (r >= d) { q++; r -= d; }
-}
-template <bool DENSE>
-__global__ __launch_bounds__(CROP_THREADS) void k_crops_sums(SegState S, int n_saved, const int32_t *__restrict__ geo,
-                                                    const long long *__restrict__ crop_off, const long long *__restrict__ band_off,
-                                                    const int32_t *__restrict__ objflag, const uint8_t *__restrict__ cleaned,
-                                                    const uint8_t *__restrict__ raw, uint8_t *__restrict__ c_raw,
-                                                    uint8_t *__restrict__ c_masked, uint8_t *__restrict__ c_mask, long long *sums,
-                                                    const long long *__restrict__ row_off, int32_t *__restrict__ rowext,
-                                                    const int32_t *__restrict__ band_obj, const uint8_t *__restrict__ dense_mask,
-                                                    const int32_t *__restrict__ band_desc)
-{
-    __shared__ uint32_t mbuf[CROP_LDS_WORDS];             // mask bits of rows r0-2 .. r1+1 (zero outside the window)
-    __shared__ uint32_t bd[CROP_LDS_WORDS];               // 4-neighbour border bits of rows r0-1 .. r1
-    __shared__ uint32_t acc[32];                          // block totals (see the end of the kernel)
-    const long long bid = blockIdx.x;
-    int s, f, bx, by, w, h, root, wpr, r0;
-    long long coff, roff;
-    if (band_desc) {                                      // (k_band_map's descriptor: block-uniform, one load)
-        const int32_t *d = band_desc + BAND_DESC_INTS * (size_t)bid;
-        f = d[0]; bx = d[1]; by = d[2]; w = d[3]; h = d[4]; root = d[5]; wpr = d[6]; s = d[7]; r0 = d[8];
-        coff = (long long)(((unsigned long long)(uint32_t)d[11] << 32) | (uint32_t)d[10]);
-        roff = (long long)(((unsigned long long)(uint32_t)d[13] << 32) | (uint32_t)d[12]);
-    } else {                                              // pseg_regionprops: band -> object -> geometry
-        s = band_obj[bid];                                // band_off[s] <= blockIdx.x < band_off[s+1]
-        const int32_t *o = geo + 8 * (size_t)s;
-        f = o[0]; bx = o[1]; by = o[2]; w = o[3]; h = o[4]; root = o[5]; wpr = o[6];
-        r0 = (int)(bid - band_off[s]) * crop_rows_per_band(w);
-        coff = crop_off[s]; roff = row_off[s];
-    }
-    const int rpb = crop_rows_per_band(w);
-    const int r1 = (r0 + rpb < h) ? r0 + rpb : h;
-    const int nrows = r1 - r0;
-    const float rcp_wpr = 1.0f / (float)wpr, rcp_wpr1 = 1.0f / (float)(wpr + 1);
-    for (int wi = threadIdx.x; wi < (nrows + 4) * wpr; wi += CROP_THREADS) mbuf[wi] = 0;
-    if (threadIdx.x < 32) acc[threadIdx.x] = threadIdx.x == 15 ? 255u : 0u;    // acc[15] = running minimum
-    __syncthreads();
-    if (DENSE) {
-        // pseg_regionprops: the mask is a dense uint8 image (nonzero = set) of row stride S.W instead of the run tables
-        for (int wi = threadIdx.x; wi < (nrows + 4) * wpr; wi += CROP_THREADS) {
-            const int yl = wi / wpr, wx = wi - yl * wpr, yy = r0 - 2 + yl;
-            uint32_t v = 0;
-            if (yy >= 0 && yy < h) {
-                const uint8_t *mrow8 = dense_mask + (size_t)(by + yy) * S.W + bx + 32 * wx;
-                const int nb = w - 32 * wx < 32 ? w - 32 * wx : 32;
-                for (int k = 0; k < nb; k++) v |= (uint32_t)(mrow8[k] != 0) << k;
-            }
-            mbuf[wi] = v;
-        }
-    } else {
-        // 16 threads per row walk the row's runs; a run paints itself and the gap on its left when the object that fills
-        // them (ext / gapl) is saved and was iterated at or before this one.  Two dependent global loads per row.
-        const int sub = threadIdx.x & (CROP_TPR - 1), x_lo = bx, x_hi = bx + w - 1;
-        auto paint = [&](uint32_t *mrow, int xa, int xb) {
-            int la = (xa > x_lo ? xa : x_lo) - bx, lb = (xb < x_hi ? xb : x_hi) - bx;
-            for (int wd = la >> 5; wd <= (lb >> 5); wd++) {
-                int ba = la > 32 * wd ? la - 32 * wd : 0, bb = lb < 32 * wd + 31 ? lb - 32 * wd : 31;
-                uint32_t m = (bb - ba == 31) ? 0xffffffffu : (((1u << (bb - ba + 1)) - 1u) << ba);
-                atomicOr(&mrow[wd], m);
-            }
-        };
-        for (int yl = threadIdx.x / CROP_TPR; yl < nrows + 4; yl += CROP_THREADS / CROP_TPR) {
-            const int yy = r0 - 2 + yl;
-            if (yy < 0 || yy >= h) continue;
-            const int rs = seg_rowstart(S, f, by + yy), n = seg_rowcount(S, f, by + yy);
-            uint32_t *mrow = mbuf + yl * wpr;
-            for (int j = sub; j < n; j += CROP_TPR) {
-                const int r = rs + j;
-                const uint32_t rx = S.run_x[r];
-                const int xs = (int)(rx & 0xffffu), xe = (int)(rx >> 16);
-                const int pe = j > 0 ? run_xe(S, r - 1) : x_hi;      // j == 0: the leading gap belongs to no object
-                const int idr = S.ext[r], idg = S.gapl[r];
-                // (the object itself is saved by definition: the flag is only looked up for other objects inside the window)
-                if (xe >= x_lo && xs <= x_hi && (idr == root || (idr > root && (objflag[idr] & 2)))) paint(mrow, xs, xe);
-                if (xs - 1 >= x_lo && pe + 1 <= x_hi && (idg == root || (idg > root && (objflag[idg] & 2)))) paint(mrow, pe + 1, xs - 1);
-            }
-        }
-    }
-    __syncthreads();
-    // border = mask minus its erosion by the 4-neighbour cross, zero outside the window
-    // (skimage perimeter(image, 4): binary_erosion(..., border_value=0), _regionprops_utils.py:225-231)
-    for (int wi = threadIdx.x; wi < (nrows + 2) * wpr; wi += CROP_THREADS) {
-        int yl, wx;                                        // row r0-1+yl  ->  mbuf row yl+1
-        divmod_small(wi, wpr, rcp_wpr, yl, wx);
-        const uint32_t *m = mbuf + __umul24((uint32_t)(yl + 1), (uint32_t)wpr);
-        uint32_t c = m[wx], up = m[wx - wpr], dn = m[wx + wpr];
-        uint32_t lf = (c << 1) | (wx > 0 ? m[wx - 1] >> 31 : 0u);
-        uint32_t rt = (c >> 1) | (wx + 1 < wpr ? m[wx + 1] << 31 : 0u);
-        bd[wi] = c & ~(up & dn & lf & rt);
-    }
-    __syncthreads();
-    const uint32_t *mb = mbuf + 2 * wpr;                  // row r0 of the band
-    const size_t P = (size_t)S.H * S.W;
-    const bool same = (raw == cleaned);                   // fused path: the Crops/ plane is cut from the same image
-    // block-uniform bases; per-item offsets stay 32-bit
-    const uint8_t *sb = cleaned + (size_t)f * P + (size_t)(by + r0) * S.W + bx;
-    const uint8_t *rb = raw + (size_t)f * P + (size_t)(by + r0) * S.W + bx;
-    const long long off = coff + (long long)r0 * w;
-    uint8_t *o_raw = c_raw + off, *o_mask = c_mask + off, *o_masked = c_masked + off;
-    uint32_t isum = 0, mn_e = 0x00ff00ffu, mn_o = 0x00ff00ffu, mx_e = 0, mx_o = 0;   // intensities: byte lanes as u16 pairs
-    if (w >= 16) {
-        // thread = 16 consecutive pixels of a row (the 8-pixel form below with 128-bit accesses)
-        const int cpr = (w + 15) >> 4, nitem = nrows * cpr;
-        const float rcp = 1.0f / (float)cpr;
-#pragma unroll CROP_UNROLL
-        for (int p = threadIdx.x; p < nitem; p += CROP_THREADS) {
-            int yl = (int)((float)p * rcp);
-            int c = p - (int)__umul24((uint32_t)yl, (uint32_t)cpr);
-            if (c < 0) { yl--; c += cpr; } else if (c >= cpr) { yl++; c -= cpr; }
-            int xx = 16 * c;
-            const int over = xx - (w - 16);               // > 0 only for the last chunk of a row when w % 16 != 0
-            if (over > 0) xx = w - 16;
-            const uint32_t *mw = mb + __umul24((uint32_t)yl, (uint32_t)wpr) + (xx >> 5);
-            const uint32_t bits16 = __builtin_amdgcn_alignbit(mw[1], mw[0], (uint32_t)(xx & 31)) & 0xffffu;
-            const uint32_t so = __umul24((uint32_t)yl, (uint32_t)S.W) + (uint32_t)xx, qo = __umul24((uint32_t)yl, (uint32_t)w) + (uint32_t)xx;
-            uint32_t cv[4], rv[4], m[4], cm[4];
-            __builtin_memcpy(cv, sb + so, 16);
-            if (same) { rv[0] = cv[0]; rv[1] = cv[1]; rv[2] = cv[2]; rv[3] = cv[3]; } else __builtin_memcpy(rv, rb + so, 16);
-#pragma unroll
-            for (int d = 0; d < 4; d++) {
-                const uint32_t m1 = __umul24((bits16 >> (4 * d)) & 0xfu, 0x00204081u) & 0x01010101u;
-                m[d] = (m1 << 8) - m1;
-                cm[d] = (cv[d] & m[d]) | ~m[d];
-            }
-            __builtin_memcpy(o_raw + qo, rv, 16);
-            __builtin_memcpy(o_mask + qo, m, 16);
-            __builtin_memcpy(o_masked + qo, cm, 16);
-#pragma unroll
-            for (int d = 0; d < 4; d++) {
-                const int nb = over - 4 * d;              // bytes of this dword that belong to the neighbour chunk
-                const uint32_t keep = nb <= 0 ? 0xffffffffu : (nb >= 4 ? 0u : 0xffffffffu << (8 * nb));
-                const uint32_t mk = m[d] & keep, in4 = cv[d] & mk, out4 = cv[d] | ~mk;
-                isum = __builtin_amdgcn_sad_u8(in4, 0u, isum);
-                mx_e = pkmax(mx_e, __builtin_amdgcn_perm(0, in4, 0x0c020c00)); mx_o = pkmax(mx_o, __builtin_amdgcn_perm(0, in4, 0x0c030c01));
-                mn_e = pkmin(mn_e, __builtin_amdgcn_perm(0, out4, 0x0c020c00)); mn_o = pkmin(mn_o, __builtin_amdgcn_perm(0, out4, 0x0c030c01));
-            }
-        }
-    } else if (w >= 8) {
-        // thread = 8 consecutive pixels of a row: one (unaligned) 64-bit load / store per plane; the last chunk of a row is
-        // shifted back to end at the row end, `keep` drops the bytes it shares with its neighbour from the sums (as below;
-        // half the index arithmetic and half the memory instructions per pixel of the 4-pixel form)
-        const int cpr = (w + 7) >> 3, nitem = nrows * cpr;
-        const float rcp = 1.0f / (float)cpr;
-#pragma unroll CROP_UNROLL
-        for (int p = threadIdx.x; p < nitem; p += CROP_THREADS) {
-            int yl = (int)((float)p * rcp);
-            int c = p - (int)__umul24((uint32_t)yl, (uint32_t)cpr);
-            if (c < 0) { yl--; c += cpr; } else if (c >= cpr) { yl++; c -= cpr; }
-            int xx = 8 * c;
-            const int over = xx - (w - 8);                // > 0 only for the last chunk of a row when w % 8 != 0
-            uint32_t keep_lo = 0xffffffffu, keep_hi = 0xffffffffu;
-            if (over > 0) {
-                xx = w - 8;
-                if (over >= 4) { keep_lo = 0; keep_hi = over > 4 ? 0xffffffffu << (8 * (over - 4)) : 0xffffffffu; }
-                else keep_lo <<= 8 * over;
-            }
-            const uint32_t *mw = mb + __umul24((uint32_t)yl, (uint32_t)wpr) + (xx >> 5);
-            const uint32_t bits8 = __builtin_amdgcn_alignbit(mw[1], mw[0], (uint32_t)(xx & 31)) & 0xffu;
-            const uint32_t so = __umul24((uint32_t)yl, (uint32_t)S.W) + (uint32_t)xx, qo = __umul24((uint32_t)yl, (uint32_t)w) + (uint32_t)xx;
-            const uint32_t m1a = __umul24(bits8 & 0xfu, 0x00204081u) & 0x01010101u, m1b = __umul24(bits8 >> 4, 0x00204081u) & 0x01010101u;
-            uint2 m8 = make_uint2((m1a << 8) - m1a, (m1b << 8) - m1b);
-            uint2 cv8, rv8;
-            __builtin_memcpy(&cv8, sb + so, 8);
-            if (same) rv8 = cv8; else __builtin_memcpy(&rv8, rb + so, 8);
-            const uint2 cm8 = make_uint2((cv8.x & m8.x) | ~m8.x, (cv8.y & m8.y) | ~m8.y);
-            __builtin_memcpy(o_raw + qo, &rv8, 8);
-            __builtin_memcpy(o_mask + qo, &m8, 8);
-            __builtin_memcpy(o_masked + qo, &cm8, 8);
-            const uint32_t mka = m8.x & keep_lo, mkb = m8.y & keep_hi;
-            const uint32_t ina = cv8.x & mka, inb = cv8.y & mkb, outa = cv8.x | ~mka, outb = cv8.y | ~mkb;
-            isum = __builtin_amdgcn_sad_u8(ina, 0u, __builtin_amdgcn_sad_u8(inb, 0u, isum));
-            mx_e = pkmax(mx_e, pkmax(__builtin_amdgcn_perm(0, ina, 0x0c020c00), __builtin_amdgcn_perm(0, inb, 0x0c020c00)));
-            mx_o = pkmax(mx_o, pkmax(__builtin_amdgcn_perm(0, ina, 0x0c030c01), __builtin_amdgcn_perm(0, inb, 0x0c030c01)));
-            mn_e = pkmin(mn_e, pkmin(__builtin_amdgcn_perm(0, outa, 0x0c020c00), __builtin_amdgcn_perm(0, outb, 0x0c020c00)));
-            mn_o = pkmin(mn_o, pkmin(__builtin_amdgcn_perm(0, outa, 0x0c030c01), __builtin_amdgcn_perm(0, outb, 0x0c030c01)));
-        }
-    } else if (w >= 4) {
-        // thread = 4 consecutive pixels of a row: one (unaligned) 32-bit load / store per plane.  The last chunk of a row is
-        // shifted back to end at the row end (it rewrites bytes of its neighbour with the same values); `keep` drops the
-        // bytes it shares with the neighbour from the sums.
-        const int cpr = (w + 3) >> 2, nitem = nrows * cpr;
-        const float rcp = 1.0f / (float)cpr;
-#pragma unroll CROP_UNROLL
-        for (int p = threadIdx.x; p < nitem; p += CROP_THREADS) {
-            // (products of values below 2^24 go through v_mul_u32_u24: the full 32-bit multiply runs at a quarter of the rate)
-            int yl = (int)((float)p * rcp);               // p / cpr, corrected below (p < 2^24)
-            int c = p - (int)__umul24((uint32_t)yl, (uint32_t)cpr);
-            if (c < 0) { yl--; c += cpr; } else if (c >= cpr) { yl++; c -= cpr; }
-            int xx = 4 * c;
-            const int over = xx - (w - 4);                // > 0 only for the last chunk of a row when w % 4 != 0
-            uint32_t keep = 0xffffffffu;
-            if (over > 0) { xx = w - 4; keep <<= 8 * over; }
-            const uint32_t *mw = mb + __umul24((uint32_t)yl, (uint32_t)wpr) + (xx >> 5);
-            const uint32_t bits4 = __builtin_amdgcn_alignbit(mw[1], mw[0], (uint32_t)(xx & 31)) & 0xfu;
-            const uint32_t so = __umul24((uint32_t)yl, (uint32_t)S.W) + (uint32_t)xx, qo = __umul24((uint32_t)yl, (uint32_t)w) + (uint32_t)xx;
-            const uint32_t m1 = __umul24(bits4, 0x00204081u) & 0x01010101u;       // bit k -> bit 0 of byte k
-            const uint32_t m4 = (m1 << 8) - m1;                                   // ... -> byte k = 255
-            uint32_t cv4, rv4;
-            __builtin_memcpy(&cv4, sb + so, 4);
-            if (same) rv4 = cv4; else __builtin_memcpy(&rv4, rb + so, 4);
-            const uint32_t cm4 = (cv4 & m4) | ~m4;        // where(mask, crop, 255)
-            __builtin_memcpy(o_raw + qo, &rv4, 4);
-            __builtin_memcpy(o_mask + qo, &m4, 4);
-            __builtin_memcpy(o_masked + qo, &cm4, 4);
-            const uint32_t mk = m4 & keep, in4 = cv4 & mk, out4 = cv4 | ~mk;   // masked-out bytes: 0 for sum / max, 255 for min
-            isum = __builtin_amdgcn_sad_u8(in4, 0u, isum);
-            mx_e = pkmax(mx_e, __builtin_amdgcn_perm(0, in4, 0x0c020c00)); mx_o = pkmax(mx_o, __builtin_amdgcn_perm(0, in4, 0x0c030c01));
-            mn_e = pkmin(mn_e, __builtin_amdgcn_perm(0, out4, 0x0c020c00)); mn_o = pkmin(mn_o, __builtin_amdgcn_perm(0, out4, 0x0c030c01));
-        }
-    } else {                                              // windows narrower than a dword: thread per pixel
-        for (int p = threadIdx.x; p < nrows * w; p += CROP_THREADS) {
-            const int yl = p / w, xx = p - yl * w;
-            const uint32_t bit = (mb[yl * wpr] >> xx) & 1u;
-            const uint32_t cv = sb[(size_t)yl * S.W + xx];
-            o_raw[p] = same ? (uint8_t)cv : rb[(size_t)yl * S.W + xx];
-            o_mask[p] = bit ? 255 : 0;
-            o_masked[p] = bit ? (uint8_t)cv : 255;
-            if (bit) { isum += cv; mx_e = pkmax(mx_e, cv); mn_e = pkmin(mn_e, cv | 0x00ff0000u); }
-        }
-    }
-    uint32_t imin, imax;
-    {
-        uint32_t mn = pkmin(mn_e, mn_o), mx = pkmax(mx_e, mx_o);
-        imin = (mn & 0xffffu) < (mn >> 16) ? (mn & 0xffffu) : (mn >> 16);
-        imax = (mx & 0xffffu) > (mx >> 16) ? (mx & 0xffffu) : (mx >> 16);
-    }
-    // One pass over the band's words: geometric moments and perimeter codes, both bit-parallel.
-    //  moments: for a word with bits at columns 32*wx + k,  sum k = sum_b 2^b popc(v & M_b),
-    //           sum k^2 = sum_b 4^b popc(v & M_b) + 2 sum_{b<c} 2^(b+c) popc(v & M_b & M_c); rows are band-local (yl), the
-    //           band offset r0 is folded in once per block, so every partial sum of the block fits 32 bits
-    //  perimeter codes (skimage perimeter, _regionprops_utils.py:233-249): for a border pixel the 3x3 sum with weights
-    //           [[10,2,10],[2,1,2],[10,2,10]] over the border image is 1 + 2*n4 + 10*nd; n4 / nd are counted with bit-sliced adders
-    uint32_t mo[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // n, wx n, wx^2 n, sk, wx sk, sk2, yl n, yl^2 n, yl wx n, yl sk
-    uint32_t pc1 = 0, pc2 = 0, pc3 = 0;
-    for (int wi = threadIdx.x; wi < nrows * wpr; wi += CROP_THREADS) {
-        int yl_, wx_;
-        divmod_small(wi, wpr, rcp_wpr, yl_, wx_);
-        const uint32_t yl = (uint32_t)yl_, wx = (uint32_t)wx_;
-        const uint32_t v = mb[wi];
-        if (v) {
-            const uint32_t M[5] = {0xaaaaaaaau, 0xccccccccu, 0xf0f0f0f0u, 0xff00ff00u, 0xffff0000u};
-            uint32_t n1 = (uint32_t)__popc(v), sk = 0, sk2 = 0;
-#pragma unroll
-            for (int b2 = 0; b2 < 5; b2++) {
-                uint32_t pb = (uint32_t)__popc(v & M[b2]);
-                sk += pb << b2; sk2 += pb << (2 * b2);
-#pragma unroll
-                for (int c2 = b2 + 1; c2 < 5; c2++) sk2 += (uint32_t)__popc(v & M[b2] & M[c2]) << (b2 + c2 + 1);
-            }
-            // (all factors are far below 2^24: 24-bit multiplies)
-            const uint32_t wn = __umul24(wx, n1), yn = __umul24(yl, n1);
-            mo[0] += n1; mo[1] += wn; mo[2] += __umul24(wx, wn); mo[3] += sk; mo[4] += __umul24(wx, sk); mo[5] += sk2;
-            mo[6] += yn; mo[7] += __umul24(yl, yn); mo[8] += __umul24(yl, wn); mo[9] += __umul24(yl, sk);
-        }
-        const uint32_t *bc = bd + __umul24(yl + 1, (uint32_t)wpr) + wx;     // border row r0+yl
-        const uint32_t C = bc[0];
-        if (C) {
-            const bool hl = wx > 0, hr = wx + 1 < (uint32_t)wpr;
-            const uint32_t U = bc[-wpr], D = bc[wpr];
-            const uint32_t cl1 = hl ? bc[-1] >> 31 : 0u, cr1 = hr ? bc[1] << 31 : 0u;
-            const uint32_t ul1 = hl ? bc[-wpr - 1] >> 31 : 0u, ur1 = hr ? bc[-wpr + 1] << 31 : 0u;
-            const uint32_t dl1 = hl ? bc[wpr - 1] >> 31 : 0u, dr1 = hr ? bc[wpr + 1] << 31 : 0u;
-            const uint32_t L = (C << 1) | cl1, R = (C >> 1) | cr1;
-            const uint32_t UL = (U << 1) | ul1, UR = (U >> 1) | ur1, DL = (D << 1) | dl1, DR = (D >> 1) | dr1;
-            // a + b + c + d per bit position -> three bit planes
-            auto add4 = [](uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t &s0, uint32_t &s1, uint32_t &s2) {
-                uint32_t h1 = a ^ b, c1 = a & b, h2 = c ^ d, c2 = c & d, t = h1 & h2;
-                s0 = h1 ^ h2; s1 = c1 ^ c2 ^ t; s2 = c1 & c2;
-            };
-            uint32_t a0, a1, a2, d0, d1, d2;
-            add4(L, R, U, D, a0, a1, a2);
-            add4(UL, UR, DL, DR, d0, d1, d2);
-            const uint32_t n4_1 = a0 & ~a1 & ~a2, n4_0 = ~(a0 | a1 | a2);
-            pc1 += (uint32_t)__popc(C & a1 & ~(d2 | (d1 & d0)));                       // n4 in {2,3}, nd <= 2: codes 5,7,15,17,25,27 -> 1
-            pc2 += (uint32_t)__popc(C & ((n4_0 & ~d0 & d1) | (n4_1 & d0 & d1)));       // codes 21,33 -> sqrt(2)
-            pc3 += (uint32_t)__popc(C & n4_1 & (d0 ^ d1) & ~d2);                       // codes 13,23 -> (1+sqrt(2))/2
-        }
-    }
-    // Euler number, 8-connectivity (skimage euler_number, _regionprops_utils.py:140-181): 2x2 quads of the
-    // zero-padded window; code 8 = only top-left set, 6 = top-right + bottom-left, 14 = all but bottom-right
-    int eul = 0;
-    {
-        const int ylast = (r1 == h) ? nrows + 1 : nrows;   // the last band also owns the quads below the window
-        for (int wi = threadIdx.x; wi < ylast * (wpr + 1); wi += CROP_THREADS) {
-            int yl, wx;
-            divmod_small(wi, wpr + 1, rcp_wpr1, yl, wx);
-            const uint32_t *B = mbuf + __umul24((uint32_t)(yl + 2), (uint32_t)wpr), *T = B - wpr;     // bottom row r0+yl, top row r0+yl-1
-            uint32_t tr = wx < wpr ? T[wx] : 0u, br = wx < wpr ? B[wx] : 0u;
-            uint32_t tl = (tr << 1) | (wx > 0 ? T[wx - 1] >> 31 : 0u), bl = (br << 1) | (wx > 0 ? B[wx - 1] >> 31 : 0u);
-            eul += __popc(tl & ~tr & ~bl & ~br) - __popc(~tl & tr & bl & ~br) - __popc(tl & tr & bl & ~br);
-        }
-    }
-    // first / last set column of every row of the band (input of the convex hull kernel)
-    for (int yl = threadIdx.x; yl < nrows; yl += CROP_THREADS) {
-        const uint32_t *m = mb + yl * wpr;
-        int first = 0x7fffffff, last = -1;
-        for (int wx = 0; wx < wpr; wx++) if (m[wx]) { first = 32 * wx + __ffs(m[wx]) - 1; break; }
-        for (int wx = wpr - 1; wx >= 0; wx--) if (m[wx]) { last = 32 * wx + 31 - __clz(m[wx]); break; }
-        rowext[2 * (roff + r0 + yl)] = first;
-        rowext[2 * (roff + r0 + yl) + 1] = last;
-    }
-    // block totals: DPP wave sums (every partial fits 32 bits, see above), lane 63 adds them into LDS, one thread flushes
-    // with 64-bit integer atomics (exact, order-independent)
-#pragma unroll
-    for (int k = 0; k < 10; k++) mo[k] = wave_sum63(mo[k]);
-    isum = wave_sum63(isum); pc1 = wave_sum63(pc1); pc2 = wave_sum63(pc2); pc3 = wave_sum63(pc3);
-    const uint32_t eulw = wave_sum63((uint32_t)eul);
-    for (int o2 = 32; o2 > 0; o2 >>= 1) {
-        uint32_t t0 = __shfl_xor(imin, o2, 64), t1 = __shfl_xor(imax, o2, 64);
-        imin = t0 < imin ? t0 : imin; imax = t1 > imax ? t1 : imax;
-    }
-    if ((threadIdx.x & 63) == 63) {
-#pragma unroll
-        for (int k = 0; k < 10; k++) if (mo[k]) atomicAdd(&acc[k], mo[k]);
-        if (isum) atomicAdd(&acc[10], isum);
-        if (pc1) atomicAdd(&acc[11], pc1);
-        if (pc2) atomicAdd(&acc[12], pc2);
-        if (pc3) atomicAdd(&acc[13], pc3);
-        if (eulw) atomicAdd(&acc[14], eulw);
-        atomicMin(&acc[15], imin); atomicMax(&acc[16], imax);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned long long *q = (unsigned long long *)(sums + (size_t)s * PSEG_NSUMS);
-        const unsigned long long N = acc[0], R0 = (unsigned long long)r0;
-        if (N) {
-            const unsigned long long sx = 32ull * acc[1] + acc[3];                                    // sum c
-            const unsigned long long sx2 = 1024ull * acc[2] + 64ull * acc[4] + acc[5];                // sum c^2
-            const unsigned long long sy = acc[6], sy2 = acc[7], syx = 32ull * acc[8] + acc[9];        // band-local rows
-            atomicAdd(&q[0], N); atomicAdd(&q[1], R0 * N + sy); atomicAdd(&q[2], sx);
-            atomicAdd(&q[3], R0 * R0 * N + 2ull * R0 * sy + sy2); atomicAdd(&q[4], sx2); atomicAdd(&q[5], R0 * sx + syx);
-        }
-        if (acc[10]) atomicAdd(&q[8], (unsigned long long)acc[10]);
-        if (acc[15] < 255u) atomicMin((long long *)&q[6], (long long)acc[15]);
-        if (acc[16] > 0u) atomicMax((long long *)&q[7], (long long)acc[16]);
-        if (acc[11]) atomicAdd(&q[10], (unsigned long long)acc[11]);
-        if (acc[12]) atomicAdd(&q[11], (unsigned long long)acc[12]);
-        if (acc[13]) atomicAdd(&q[12], (unsigned long long)acc[13]);
-        if (acc[14]) atomicAdd(&q[13], (unsigned long long)(long long)(int)acc[14]);
-    }
-}
-
-// Convex hull area (skimage convex_hull_image, morphology/convex_hull.py:73-145): hull of the +-0.5 "diamond"
-// points of the row-extremal pixels, then every pixel centre inside or on the hull.  In doubled coordinates
-// R' = 2*row + 1 (+-1), X = 2*col (+-1) the hull's left chain is the lower convex envelope of the profile L(R') and
-// the right chain the upper envelope of U(R'):  odd R' = pixel row r (points (2r, 2c -+ 1)), even R' = between rows
-// r-1 and r ((2r-1, 2c) of either row).  Wave 0 builds the left chain, wave 1 the right chain, by divide and conquer:
-// every lane takes a contiguous piece of the profile and builds its strict hull with a monotone chain (doubly linked
-// list in LDS); six rounds then merge neighbouring hulls pairwise -- one lane per pair walks the two tangent points
-// outwards from the junction (cost = vertices removed + 1).  Lane 0 reads the final list into a vertex array, and
-// every pixel row finds its hull edge by binary search and gets its column bound with one division.  Exact 32-bit
-// cross products: |dX| < 2^15, |dR'| < 2^14 for the heights the LDS admits; collinear points are dropped.
-// Dynamic LDS: 56 bytes per row of the tallest object served by the launch (the host launches one size class per
-// call so that small objects keep a high occupancy).
-#define HULL_LDS_PER_ROW 28
-typedef short hull_t;                // profile values (|X| <= 2 * 8191 + 1, sentinels +-20000) and list links (< 2 * 2700 + 2) fit 16 bits
-template <bool LOWER>
-__device__ __forceinline__ bool hull_drop(int ra, int va, int rb, int vb, int rc, int vc)   // b is no strict vertex between a and c
-{
-    const int d = (rb - ra) * (vc - va) - (vb - va) * (rc - ra);
-    return LOWER ? d <= 0 : d >= 0;
-}
-__device__ __forceinline__ void hull_wave_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-template <bool LOWER>
-__device__ __forceinline__ void hull_chain(const hull_t *pv, int np, volatile hull_t *nxt, volatile hull_t *prv, hull_t *bound, int h, int lane)
-{
-    const int seg = (np + 63) >> 6;
-    {   // strict hull of the lane's piece [s0, s1)
-        const int s0 = lane * seg, s1 = s0 + seg < np ? s0 + seg : np;
-        if (s0 < np) {
-            int top = s0, vtop = pv[s0];
-            prv[s0] = -1;
-            for (int c = s0 + 1; c < s1; c++) {
-                const int vc = pv[c];
-                for (;;) {
-                    const int p = prv[top];
-                    if (p < 0 || !hull_drop<LOWER>(p, pv[p], top, vtop, c, vc)) break;
-                    top = p; vtop = pv[p];
-                }
-                prv[c] = (hull_t)top; nxt[top] = (hull_t)c; top = c; vtop = vc;
-            }
-            nxt[top] = -1;
-        }
-    }
-    for (int s = 1; s < 64; s <<= 1) {                      // merge the hulls of lanes [l, l+s) and [l+s, l+2s)
-        hull_wave_sync();
-        const int vstart = (lane + s) * seg;
-        if ((lane & (2 * s - 1)) == 0 && vstart < np) {
-            int v = vstart, u = vstart - 1, vu = pv[u], vv = pv[v];
-            for (;;) {
-                bool moved = false;
-                int pu = prv[u];
-                while (pu >= 0 && hull_drop<LOWER>(pu, pv[pu], u, vu, v, vv)) { u = pu; vu = pv[u]; pu = prv[u]; moved = true; }
-                int nv = nxt[v];
-                while (nv >= 0 && hull_drop<LOWER>(u, vu, v, vv, nv, pv[nv])) { v = nv; vv = pv[v]; nv = nxt[v]; moved = true; }
-                if (!moved) break;
-            }
-            nxt[u] = (hull_t)v; prv[v] = (hull_t)u;
-        }
-    }
-    hull_wave_sync();
-    hull_t *vl = (hull_t *)prv;                             // vertex array over the (now dead) back links: vl[k] sits at or before vertex k
-    int nv = 0;
-    if (lane == 0) for (int i = 0; i >= 0; i = nxt[i]) vl[nv++] = (hull_t)i;
-    nv = __builtin_amdgcn_readfirstlane(nv);
-    hull_wave_sync();
-    for (int r = lane; r < h; r += 64) {                    // pixel row r = profile index 2r+1
-        const int i = 2 * r + 1;
-        int lo = 0, hi = nv - 1;                            // edge k with vl[k] < i <= vl[k+1]
-        while (hi - lo > 1) { const int m = (lo + hi) >> 1; if (vl[m] < i) lo = m; else hi = m; }
-        const int ea = vl[lo], eb = vl[hi], xa = pv[ea], xb = pv[eb];
-        const int den = eb - ea, twoden = 2 * den;
-        const int num = xa * den + (xb - xa) * (i - ea);    // 2 * den * X on the edge; column = X / 2
-        const int c = LOWER ? (num >= 0 ? (num + twoden - 1) / twoden : -((-num) / twoden))      // ceil
-                            : (num >= 0 ? num / twoden : -((-num + twoden - 1) / twoden));       // floor
-        bound[2 * r + (LOWER ? 0 : 1)] = (hull_t)c;
-    }
-}
-__global__ __launch_bounds__(128) void k_convex(int n_saved, const int32_t *__restrict__ geo, const long long *__restrict__ row_off,
-                                                const int32_t *__restrict__ rowext, long long *sums, int hlo, int hhi)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char hull_smem[];
-    const int s = blockIdx.x;
-    const int h = geo[8 * (size_t)s + 4];
-    if (h <= hlo || h > hhi) return;                        // another size class
-    const int np = 2 * h + 1;
-    hull_t *fl = (hull_t *)hull_smem;                       // first / last column per row (last = -1: empty row); later the two column bounds
-    const int npm = 2 * hhi + 1;
-    hull_t *pvl = fl + 2 * hhi, *pvu = pvl + npm, *nxl = pvu + npm, *prl = nxl + npm, *nxu = prl + npm, *pru = nxu + npm;
-    long long *q = sums + (size_t)s * PSEG_NSUMS;
-    const int32_t *re = rowext + 2 * row_off[s];
-    for (int i = threadIdx.x; i < 2 * h; i += 128) { const int v = re[i]; fl[i] = (hull_t)(v > 32767 ? 32767 : v); }   // (first = INT_MAX in empty rows)
-    __syncthreads();
-    // rows without a set pixel (possible between the components of a dense mask, pseg_regionprops) give no hull points:
-    // their profile values lie beyond every real column, small enough for the 32-bit cross products
-    const int LINF = 20000, UINF = -20000;
-    for (int i = threadIdx.x; i < np; i += 128) {
-        const int r = i >> 1;
-        int l, u;
-        auto lo_of = [&](int row) { return (row >= 0 && row < h && fl[2 * row + 1] >= 0) ? 2 * fl[2 * row] : LINF; };
-        auto hi_of = [&](int row) { return (row >= 0 && row < h && fl[2 * row + 1] >= 0) ? 2 * fl[2 * row + 1] : UINF; };
-        if (i & 1) {
-            const bool has = fl[2 * r + 1] >= 0;
-            l = has ? 2 * fl[2 * r] - 1 : LINF; u = has ? 2 * fl[2 * r + 1] + 1 : UINF;
-        } else {
-            const int la = lo_of(r - 1), lb = lo_of(r), ua = hi_of(r - 1), ub = hi_of(r);
-            l = la < lb ? la : lb; u = ua > ub ? ua : ub;
-        }
-        pvl[i] = (hull_t)l; pvu[i] = (hull_t)u;
-    }
-    __syncthreads();
-    if (threadIdx.x < 64) hull_chain<true>(pvl, np, nxl, prl, fl, h, threadIdx.x);
-    else hull_chain<false>(pvu, np, nxu, pru, fl, h, threadIdx.x - 64);
-    __syncthreads();
-    unsigned long long cnt = 0;
-    for (int r = threadIdx.x; r < h; r += 128)
-        if (fl[2 * r + 1] >= fl[2 * r]) cnt += (unsigned long long)(fl[2 * r + 1] - fl[2 * r] + 1);
-    cnt = wave_sum_u64(cnt);
-    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd((unsigned long long *)&q[14], cnt);
-}
-__global__ void k_init_sums(long long *sums, int n_saved)
-{
-    size_t g = GTID;
-    if (g >= (size_t)n_saved * PSEG_NSUMS) return;
-    sums[g] = (g % PSEG_NSUMS == 6) ? 255 : 0;             // min intensity starts at 255
-}
+#include "kernels_dense.h"
+#include "kernels_labelling.h"
+#include "kernels_output.h"
 
 // ------------------------------------------------------------------------------------------------
 // host side
