@@ -123,7 +123,7 @@ __global__ void k_unions(SegState S, int nfg, int nt, int bandh)
 // batch, [F + 1] = largest band, [F + 2] = error flag of the look-back scan.
 __device__ __forceinline__ bool chain_ok(const SegState &S, uint32_t cap, uint32_t bcap)
 {
-    return S.framebase[S.F] <= cap && S.framebase[S.F + 1] <= bcap;
+    return S.framebase[S.F] <= cap && S.framebase[S.F + 1] <= bcap && S.framebase[S.F + 2] == 0;   // (a scan that timed out left no usable tables)
 }
 // unions across the band boundaries only: block = the first row of a band (y = BAND_H, 2 BAND_H, ...) of one frame, a
 // thread per run (its foreground unions with the row above, and the gap on its left) plus one for the trailing gap.  The
@@ -251,9 +251,21 @@ __global__ __launch_bounds__(256) void k_band_label(SegState S)
 // beyond `cap` entries (the totals still come out right; the host then grows the buffers and launches again).  A band with
 // more than BAND_CAP runs skips the LDS labelling and writes its runs directly; bandmax tells the host to label globally.
 // scan[0] = ticket counter, scan[2 + t] = state of block t: flag << 62 | value.  All cleared by k_reduce_partials.
+// Ticket modes (order): BAND_ORDER_TICKET = one atomic on scan[0] per block, which is what makes the scan safe on any
+// dispatcher (a ticket is only ever held by a running block).  8000 blocks asking one word of device memory for a number is
+// 45 of the kernel's 158 us, so the default is BAND_ORDER_INDEX: ticket = block index.  That is safe where blocks start in
+// index order on every XCD (then the unfinished block with the smallest index is always running: the blocks that hold its
+// XCD's slots have smaller indices and wait for nothing unfinished) -- how the hardware dispatches a 1-D grid, but not a
+// documented promise, so it is not trusted: the spin bound is short in this mode, and the host answers the timeout flag by
+// running the batch again with tickets and keeping them for the rest of the context's life (no wrong result, no hang).
+// BAND_ORDER_TEST raises the timeout flag without waiting (the host's way back is under test in tests/test_gpu_async.py).
 #define SCAN_AGG (1ull << 62)
 #define SCAN_INC (2ull << 62)
 #define SCAN_SPIN_MAX (1 << 22)
+#define SCAN_SPIN_MAX_INDEX (1 << 18)
+#define BAND_ORDER_TICKET 0
+#define BAND_ORDER_INDEX 1
+#define BAND_ORDER_TEST 2
 #ifndef LB_K
 #define LB_K 1                        // look-back windows (of 256 predecessor blocks) read per round (4: 0.179 ms against 0.157 ms)
 #endif
@@ -273,7 +285,7 @@ __device__ unsigned long long g_band_prof[16];
 #endif
 template <int WPL, int CAP>
 __global__ __launch_bounds__(256) void k_runs_band(SegState S, int wpl, uint32_t cap, unsigned long long *__restrict__ scan,
-                                                   uint32_t *__restrict__ bandmax)
+                                                   uint32_t *__restrict__ bandmax, int order)
 {
 #ifdef BAND_PROF
     unsigned long long stamp_ = wall_clock64();
@@ -287,10 +299,13 @@ __global__ __launch_bounds__(256) void k_runs_band(SegState S, int wpl, uint32_t
     __shared__ uint32_t wtot[4];
     __shared__ uint32_t s_ticket, s_base;
     const int H = S.H, nbpf = (H + BAND_H - 1) / BAND_H;
-    if (threadIdx.x == 0) s_ticket = (uint32_t)atomicAdd(&scan[0], 1ull);
-    __syncthreads();
+    if (order == BAND_ORDER_TICKET) {
+        if (threadIdx.x == 0) s_ticket = (uint32_t)atomicAdd(&scan[0], 1ull);
+        __syncthreads();
+    }
     BAND_STAMP(0);                                        // ticket
-    const int t = (int)s_ticket;
+    const int t = order == BAND_ORDER_TICKET ? (int)s_ticket : (int)blockIdx.x;
+    const int spin_max = order == BAND_ORDER_TICKET ? SCAN_SPIN_MAX : SCAN_SPIN_MAX_INDEX;
     const int f = t / nbpf, band = t - f * nbpf, y0 = band * BAND_H;
     const int nr = (y0 + BAND_H <= H) ? BAND_H : H - y0;  // rows in this band
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, part = lane & 3;
@@ -323,6 +338,7 @@ __global__ __launch_bounds__(256) void k_runs_band(SegState S, int wpl, uint32_t
         __hip_atomic_store(&scan[2 + t], (t == 0 ? SCAN_INC : SCAN_AGG) | nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (t == 0) s_base = 0;
         if (nb > *(volatile uint32_t *)bandmax) atomicMax(bandmax, nb);      // (a stale read only costs a redundant atomic)
+        if (order == BAND_ORDER_TEST && t == 1) bandmax[1] = 1;
         lrow[BAND_H] = (int)nb;
     }
     const uint32_t li = wbase + incl - cnt;               // band-local index of the lane's first run
@@ -419,7 +435,7 @@ __global__ __launch_bounds__(256) void k_runs_band(SegState S, int wpl, uint32_t
             for (int k = 0; k < LB_K; k++) {
                 const int idx = pos - 256 * k - (int)threadIdx.x;
                 int spins = 0;
-                while ((sv[k] >> 62) == 0 && ++spins < SCAN_SPIN_MAX) {
+                while ((sv[k] >> 62) == 0 && ++spins < spin_max) {
                     __builtin_amdgcn_s_sleep(2);
                     sv[k] = __hip_atomic_load(&scan[2 + idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }

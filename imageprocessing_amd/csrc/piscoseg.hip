@@ -77,6 +77,10 @@ struct pseg_ctx {
     bool have_bits = false;       // threshold plane + masked sums already produced by the bg kernel
     DevBuf bounds, band_off, band_obj /* one 64-byte descriptor per crop band: k_band_map */, trash, rp_small, rp_scratch, resize_tab, synth_objs, synth_off;
     int bounds_n = -1, bounds_emit = -1, bounds_chunks = -1, bounds_batch = -1;
+    int band_order = 1;           // k_runs_band's scan order: 1 = block index (BAND_ORDER_INDEX; falls back to 0 = tickets for good when
+                                  // a scan times out), 2 = raise the timeout flag once (test of the fallback); PSEG_BAND_ORDER
+    int band_test_call = -1, detect_calls = 0;   // PSEG_BAND_ORDER=3: index order, and mode 2 on the context's third batch (a queued chain)
+    int band_fallbacks = 0;       // times the index order was given up (pseg_tuning_state)
     bool runs_old = false;        // PSEG_RUNS_OLD=1: two-pass run extraction (k_runs) + k_band_label instead of the fused k_runs_band
     bool exclusive = true;        // the device part of a call holds the GPU's turn (PSEG_EXCLUSIVE=0: batches interleave freely)
     bool shared_stream = false;   // PSEG_SHARED_STREAM=1: the streaming parts of all contexts go through one stream per device (GpuTurn)
@@ -228,6 +232,11 @@ extern "C" int pseg_create(int device, int H, int W, int max_frames, pseg_ctx **
     if (const char *e = getenv("PSEG_EARLY_RELEASE")) ctx->early_release = atoi(e) != 0;
     if (const char *e = getenv("PSEG_SHARED_STREAM")) ctx->shared_stream = atoi(e) != 0;
     if (const char *e = getenv("PSEG_RUNS_OLD")) ctx->runs_old = atoi(e) != 0;
+    if (const char *e = getenv("PSEG_BAND_ORDER")) {
+        const int v = atoi(e);
+        ctx->band_order = v >= 0 && v <= 2 ? v : (v == 3 ? 1 : 0);
+        if (v == 3) ctx->band_test_call = 2;
+    }
     if (const char *e = getenv("PSEG_NO_BANDS")) ctx->no_bands = atoi(e) != 0;
     if (const char *e = getenv("PSEG_FILL_ROWS")) ctx->fill_rows = atoi(e);
     for (auto &e : ctx->ev) if (hipEventCreate(&e) != hipSuccess) { pseg_destroy(ctx); return PSEG_ERR_HIP; }   // frees what exists so far
@@ -278,6 +287,8 @@ extern "C" long long pseg_tuning_state(const pseg_ctx *ctx, int which)
     case 1: return ctx->band_cap;
     case 2: return ctx->spec_hold;
     case 3: return ctx->fill_rows >= 0 ? (ctx->fill_rows > 0) : (ctx->dense_rows ? 1 : 0);
+    case 4: return ctx->band_order;
+    case 5: return ctx->band_fallbacks;
     default: return -1;
     }
 }
@@ -662,7 +673,7 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
     };
     auto launch_fused = [&](uint32_t capv) {
         const dim3 g(nbpf * n), b(256);
-#define BAND_LAUNCH(WPL_, CAP_) hipLaunchKernelGGL((k_runs_band<WPL_, CAP_>), g, b, 0, ctx->cur, S, runs_wpl, capv, scan, bandmax_d)
+#define BAND_LAUNCH(WPL_, CAP_) hipLaunchKernelGGL((k_runs_band<WPL_, CAP_>), g, b, 0, ctx->cur, S, runs_wpl, capv, scan, bandmax_d, ctx->band_order)
         if (runs_wpl > 10) {
             if (ctx->band_cap > BAND_CAP_MID) BAND_LAUNCH(16, BAND_CAP_DENSE);
             else if (ctx->band_cap > BAND_CAP) BAND_LAUNCH(16, BAND_CAP_MID);
@@ -707,9 +718,18 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
         HIPCHK(hipGetLastError());
         return 0;
     };
+    // a look-back scan in block-index order timed out: tickets from here on (this batch again, and every later one)
+    auto band_order_fallback = [&]() -> int {
+        ctx->band_order = 0;
+        ctx->band_fallbacks++;
+        HIPCHK(hipMemsetAsync(scan, 0, (size_t)scan_words(ctx, n) * 8, ctx->cur));
+        HIPCHK(hipMemsetAsync(bandmax_d + 1, 0, 4, ctx->cur));
+        return 0;
+    };
     // Fast path: the whole chain is queued at once, sized by the tables' capacity (what the largest batch so far needed plus a
     // quarter); the host looks at the totals only when the head arrives, behind the label fill.  Slow path (first batch, a
     // denser batch, bands beyond the LDS labelling, very wide rows): totals first, then the chain.
+    if (ctx->detect_calls++ == ctx->band_test_call && ctx->band_order == 1) ctx->band_order = 2;
     bool spec = fused && !ctx->no_bands && ctx->runcap > 0 && ctx->spec_hold == 0;
     if (ctx->spec_hold > 0) ctx->spec_hold--;
     bool turn_released = false;
@@ -736,8 +756,12 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
             HIPCHK(hipEventRecord(ctx->ev[8], ctx->cur));
             HIPCHK(hipEventSynchronize(ctx->ev[8]));
             const uint32_t nfg_u = ((const volatile uint32_t *)ctx->pin_nfg.p)[0], bandmax = ((const volatile uint32_t *)ctx->pin_nfg.p)[1];
-            if (fused && ((const volatile uint32_t *)ctx->pin_nfg.p)[2] != 0)
-                return fail(ctx, PSEG_ERR_HIP, "k_runs_band: a block waited for its predecessors' totals for too long");
+            if (fused && ((const volatile uint32_t *)ctx->pin_nfg.p)[2] != 0) {
+                if (ctx->band_order == 0)
+                    return fail(ctx, PSEG_ERR_HIP, "k_runs_band: a block waited for its predecessors' totals for too long");
+                { int r_ = band_order_fallback(); if (r_) return r_; }
+                continue;
+            }
             if (nfg_u > 0x3fffffffu) return fail(ctx, PSEG_ERR_CAPACITY, "too many foreground runs");
             nfg = (int)nfg_u;
             const bool fits = fused && cap0 > 0 && nfg_u <= cap0;
@@ -779,7 +803,13 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
         HIPCHK(hipEventSynchronize(ctx->ev[3]));
         if (!spec) break;
         const HeadHost h0 = head_host(ctx, n);
-        if (h0.totals[6] != 0) return fail(ctx, PSEG_ERR_HIP, "k_runs_band: a block waited for its predecessors' totals for too long");
+        if (h0.totals[6] != 0) {
+            if (ctx->band_order == 0)
+                return fail(ctx, PSEG_ERR_HIP, "k_runs_band: a block waited for its predecessors' totals for too long");
+            { int r_ = band_order_fallback(); if (r_) return r_; }
+            spec = false;
+            continue;
+        }
         if ((unsigned long long)h0.totals[4] > 0x3fffffffull) return fail(ctx, PSEG_ERR_CAPACITY, "too many foreground runs");
         nfg = (int)h0.totals[4];
         band_seen = (uint32_t)h0.totals[5];

@@ -118,7 +118,8 @@ class Segmenter:
         """what the context has adapted to (pseg_tuning_state): run-table capacity, band size class, slow-path calls left,
         row-wise label fill for the next batch"""
         return dict(run_capacity=int(self.L.pseg_tuning_state(self.h, 0)), band_class=int(self.L.pseg_tuning_state(self.h, 1)),
-                    slow_path_calls=int(self.L.pseg_tuning_state(self.h, 2)), fill_by_rows=bool(self.L.pseg_tuning_state(self.h, 3)))
+                    slow_path_calls=int(self.L.pseg_tuning_state(self.h, 2)), fill_by_rows=bool(self.L.pseg_tuning_state(self.h, 3)),
+                    band_order=int(self.L.pseg_tuning_state(self.h, 4)), band_order_fallbacks=int(self.L.pseg_tuning_state(self.h, 5)))
 
     def last_ms(self, which):
         return float(self.L.pseg_last_ms(self.h, which))

@@ -196,7 +196,10 @@ float pseg_last_ms(const pseg_ctx *ctx, int which);
  * diagnosis): 0 = capacity of the run tables (runs; the labelling chain is queued without a host round trip while a
  * batch stays below it), 1 = size class of the band kernel (runs a 64-row band may hold for the labelling in LDS:
  * 1024, 2048 or 4096), 2 = calls for which the chain is queued only after the run count is known (after a batch too dense
- * even for the largest class), 3 = 1 when the next label map is written row-wise (dense rows), 0 span-wise.
+ * even for the largest class), 3 = 1 when the next label map is written row-wise (dense rows), 0 span-wise,
+ * 4 = order of the band kernel's look-back scan (1 = block index, the default; 0 = tickets from an atomic counter, which
+ * a context moves to for good after a scan in index order timed out -- the batch is repeated inside the call; environment
+ * PSEG_BAND_ORDER=0 starts there), 5 = times that has happened.
  * Returns -1 for a bad argument. */
 long long pseg_tuning_state(const pseg_ctx *ctx, int which);
 

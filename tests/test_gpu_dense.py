@@ -157,3 +157,46 @@ def test_density_changes_between_batches():
         assert st["band_class"] == 1024 and st["slow_path_calls"] == 0 and not st["fill_by_rows"]
     finally:
         seg.close()
+
+
+@pytest.mark.parametrize("order", ["0", "1", "2", "3"])
+def test_band_scan_order_and_its_fallback(monkeypatch, order):
+    """The band kernel's look-back scan runs in block-index order by default (PSEG_BAND_ORDER=1) and in ticket order
+    (=0) after a scan timed out; =2 makes the kernel raise the timeout flag itself on the first batch (totals first: the
+    slow path), =3 on the context's third batch (chain and label fill already queued behind it): the call repeats the batch
+    with tickets, the context stays on tickets, and every batch equals the oracle in all modes."""
+    import torch
+    from imageprocessing_amd.engine import Segmenter
+    monkeypatch.setenv("PSEG_BAND_ORDER", order)
+    H, W, n = 256, 512, 5
+    rng = np.random.default_rng(23)
+    seg = Segmenter(H, W, max_frames=n, device=0)
+
+    def batch():
+        c = np.full((n, H, W), 255, np.uint8)
+        for f in range(n):
+            for _ in range(9):
+                y, x, h, w = rng.integers(0, H - 50), rng.integers(0, W - 70), rng.integers(4, 50), rng.integers(4, 70)
+                c[f, y:y + h, x:x + w] = rng.integers(0, 200)
+        return c
+
+    def run(cleaned):
+        items = [(cleaned[f], cleaned[f], [100.0, 50.0], f"o_{f:03d}.png") for f in range(n)]
+        dets = helpers.oracle_detect(items, None, min_area_to_segment=2, min_area_to_save=30, mask_img=False)
+        labels = torch.empty((n, H, W), dtype=torch.int32, device="cuda")
+        tab = seg.detect(torch.from_numpy(cleaned).cuda(), min_area_to_segment=2, min_area_to_save=30, labels=labels, fetch_crops=True)
+        helpers.compare_table(tab, dets, H, W, labels=labels.cpu().numpy())
+        return seg.tuning_state()
+
+    try:
+        st = run(batch())                                  # first batch: totals first (slow path)
+        if order == "2":
+            assert st["band_order"] == 0 and st["band_order_fallbacks"] == 1
+        else:
+            assert st["band_order"] == min(int(order), 1) and st["band_order_fallbacks"] == 0
+        for _ in range(3):                                 # later batches: the chain is queued at once (fast path)
+            st = run(batch())
+        assert st["band_order"] == (0 if order in "23" else int(order))
+        assert st["band_order_fallbacks"] == (1 if order in "23" else 0)
+    finally:
+        seg.close()
