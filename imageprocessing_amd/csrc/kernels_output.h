@@ -15,6 +15,12 @@
 #define CROP_TPR 4                   // threads that share the runs of one row while the mask is painted (64 rows at a time;
                                      // 16 / 8 / 2 threads per row: 0.384 / 0.351 / 0.338 ms for the crop group against 0.334 ms)
 #endif
+#ifndef CROP_EXP
+#define CROP_EXP 0                   // experiments only (wrong results): 1 no flush of the sums, 2 no mask painting, 4 no pixel loop, 8 no moment / perimeter / Euler loops
+#endif
+#ifndef CROP_RPT
+#define CROP_RPT 4                   // runs of a row a thread requests together while the mask is painted
+#endif
 #ifndef CROP_LDS_WORDS
 #define CROP_LDS_WORDS 2048          // mask words of a band + 2 halo rows on each side (frames up to 8192 px wide: 8 rows of 256 words)
 #endif
@@ -324,7 +330,8 @@ __global__ __launch_bounds__(CROP_THREADS) void k_crops_sums(SegState S, int n_s
     for (int wi = threadIdx.x; wi < (nrows + 4) * wpr; wi += CROP_THREADS) mbuf[wi] = 0;
     if (threadIdx.x < 32) acc[threadIdx.x] = threadIdx.x == 15 ? 255u : 0u;    // acc[15] = running minimum
     __syncthreads();
-    if (DENSE) {
+    if (CROP_EXP & 2) {
+    } else if (DENSE) {
         // pseg_regionprops: the mask is a dense uint8 image (nonzero = set) of row stride S.W instead of the run tables
         for (int wi = threadIdx.x; wi < (nrows + 4) * wpr; wi += CROP_THREADS) {
             const int yl = wi / wpr, wx = wi - yl * wpr, yy = r0 - 2 + yl;
@@ -337,7 +344,7 @@ __global__ __launch_bounds__(CROP_THREADS) void k_crops_sums(SegState S, int n_s
             mbuf[wi] = v;
         }
     } else {
-        // 16 threads per row walk the row's runs; a run paints itself and the gap on its left when the object that fills
+        // CROP_TPR threads per row walk the row's runs; a run paints itself and the gap on its left when the object that fills
         // them (ext / gapl) is saved and was iterated at or before this one.  Two dependent global loads per row.
         const int sub = threadIdx.x & (CROP_TPR - 1), x_lo = bx, x_hi = bx + w - 1;
         auto paint = [&](uint32_t *mrow, int xa, int xb) {
@@ -353,15 +360,33 @@ __global__ __launch_bounds__(CROP_THREADS) void k_crops_sums(SegState S, int n_s
             if (yy < 0 || yy >= h) continue;
             const int rs = seg_rowstart(S, f, by + yy), n = seg_rowcount(S, f, by + yy);
             uint32_t *mrow = mbuf + yl * wpr;
-            for (int j = sub; j < n; j += CROP_TPR) {
-                const int r = rs + j;
-                const uint32_t rx = S.run_x[r];
-                const int xs = (int)(rx & 0xffffu), xe = (int)(rx >> 16);
-                const int pe = j > 0 ? run_xe(S, r - 1) : x_hi;      // j == 0: the leading gap belongs to no object
-                const int idr = S.ext[r], idg = S.gapl[r];
-                // (the object itself is saved by definition: the flag is only looked up for other objects inside the window)
-                if (xe >= x_lo && xs <= x_hi && (idr == root || (idr > root && (objflag[idr] & 2)))) paint(mrow, xs, xe);
-                if (xs - 1 >= x_lo && pe + 1 <= x_hi && (idg == root || (idg > root && (objflag[idg] & 2)))) paint(mrow, pe + 1, xs - 1);
+            // A thread takes CROP_RPT runs of the row per round: their extents (and their left neighbours') are requested
+            // together -- one memory latency per round -- and only the runs that meet the window (one or two of a dense
+            // frame's twenty per row) go on to the dependent loads: object of the run / of the gap on its left, saved flag.
+            // (One run per step with all its loads took 0.39 of the kernel's 0.75 ms on frames of 2000 objects.)
+            for (int jb = 0; jb < n; jb += CROP_RPT * CROP_TPR) {
+                uint32_t rx[CROP_RPT], px[CROP_RPT];
+#pragma unroll
+                for (int k = 0; k < CROP_RPT; k++) {
+                    const int j = jb + k * CROP_TPR + sub;
+                    rx[k] = j < n ? S.run_x[rs + j] : 0xffffu;                   // past the row's runs: xs = 65535, xe = 0
+                    px[k] = (j > 0 && j < n) ? S.run_x[rs + j - 1] : ((uint32_t)x_hi << 16);   // j == 0: the leading gap belongs to no object
+                }
+                int xs_last = 0;
+#pragma unroll
+                for (int k = 0; k < CROP_RPT; k++) {
+                    const int xs = (int)(rx[k] & 0xffffu), xe = (int)(rx[k] >> 16), pe = (int)(px[k] >> 16);
+                    const bool run_in = xe >= x_lo && xs <= x_hi, gap_in = xs - 1 >= x_lo && pe + 1 <= x_hi;
+                    xs_last = xs;
+                    if (run_in || gap_in) {
+                        const int r = rs + jb + k * CROP_TPR + sub;
+                        const int idr = S.ext[r], idg = S.gapl[r];
+                        // (the object itself is saved by definition: the flag is only looked up for other objects inside the window)
+                        if (run_in && (idr == root || (idr > root && (objflag[idr] & 2)))) paint(mrow, xs, xe);
+                        if (gap_in && (idg == root || (idg > root && (objflag[idg] & 2)))) paint(mrow, pe + 1, xs - 1);
+                    }
+                }
+                if (xs_last > x_hi) break;                   // (runs are sorted) neither the later runs nor the gaps on their left meet the window
             }
         }
     }
@@ -387,7 +412,8 @@ __global__ __launch_bounds__(CROP_THREADS) void k_crops_sums(SegState S, int n_s
     const long long off = coff + (long long)r0 * w;
     uint8_t *o_raw = c_raw + off, *o_mask = c_mask + off, *o_masked = c_masked + off;
     uint32_t isum = 0, mn_e = 0x00ff00ffu, mn_o = 0x00ff00ffu, mx_e = 0, mx_o = 0;   // intensities: byte lanes as u16 pairs
-    if (w >= 16) {
+    if (CROP_EXP & 4) {
+    } else if (w >= 16) {
         // thread = 16 consecutive pixels of a row (the 8-pixel form below with 128-bit accesses)
         const int cpr = (w + 15) >> 4, nitem = nrows * cpr;
         const float rcp = 1.0f / (float)cpr;
@@ -521,7 +547,7 @@ __global__ __launch_bounds__(CROP_THREADS) void k_crops_sums(SegState S, int n_s
     //           [[10,2,10],[2,1,2],[10,2,10]] over the border image is 1 + 2*n4 + 10*nd; n4 / nd are counted with bit-sliced adders
     uint32_t mo[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // n, wx n, wx^2 n, sk, wx sk, sk2, yl n, yl^2 n, yl wx n, yl sk
     uint32_t pc1 = 0, pc2 = 0, pc3 = 0;
-    for (int wi = threadIdx.x; wi < nrows * wpr; wi += CROP_THREADS) {
+    for (int wi = threadIdx.x; wi < ((CROP_EXP & 8) ? 0 : nrows * wpr); wi += CROP_THREADS) {
         int yl_, wx_;
         divmod_small(wi, wpr, rcp_wpr, yl_, wx_);
         const uint32_t yl = (uint32_t)yl_, wx = (uint32_t)wx_;
@@ -570,7 +596,7 @@ __global__ __launch_bounds__(CROP_THREADS) void k_crops_sums(SegState S, int n_s
     int eul = 0;
     {
         const int ylast = (r1 == h) ? nrows + 1 : nrows;   // the last band also owns the quads below the window
-        for (int wi = threadIdx.x; wi < ylast * (wpr + 1); wi += CROP_THREADS) {
+        for (int wi = threadIdx.x; wi < ((CROP_EXP & 8) ? 0 : ylast * (wpr + 1)); wi += CROP_THREADS) {
             int yl, wx;
             divmod_small(wi, wpr + 1, rcp_wpr1, yl, wx);
             const uint32_t *B = mbuf + __umul24((uint32_t)(yl + 2), (uint32_t)wpr), *T = B - wpr;     // bottom row r0+yl, top row r0+yl-1
@@ -609,7 +635,7 @@ __global__ __launch_bounds__(CROP_THREADS) void k_crops_sums(SegState S, int n_s
         atomicMin(&acc[15], imin); atomicMax(&acc[16], imax);
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && !(CROP_EXP & 1)) {
         unsigned long long *q = (unsigned long long *)(sums + (size_t)s * PSEG_NSUMS);
         const unsigned long long N = acc[0], R0 = (unsigned long long)r0;
         if (N) {

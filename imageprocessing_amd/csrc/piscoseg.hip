@@ -81,6 +81,7 @@ struct pseg_ctx {
                                   // a scan times out), 2 = raise the timeout flag once (test of the fallback); PSEG_BAND_ORDER
     int band_test_call = -1, detect_calls = 0;   // PSEG_BAND_ORDER=3: index order, and mode 2 on the context's third batch (a queued chain)
     int band_fallbacks = 0;       // times the index order was given up (pseg_tuning_state)
+    bool timing = true;           // PSEG_TIMING=0: no timing events in the stream
     bool runs_old = false;        // PSEG_RUNS_OLD=1: two-pass run extraction (k_runs) + k_band_label instead of the fused k_runs_band
     bool exclusive = true;        // the device part of a call holds the GPU's turn (PSEG_EXCLUSIVE=0: batches interleave freely)
     bool shared_stream = false;   // PSEG_SHARED_STREAM=1: the streaming parts of all contexts go through one stream per device (GpuTurn)
@@ -118,6 +119,10 @@ static int fail(pseg_ctx *c, int code, const std::string &msg)
             return fail(ctx, PSEG_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));         \
     } while (0)
 
+// events that only time the kernel groups (pseg_last_ms); PSEG_TIMING=0 leaves them out (each is a few microseconds of idle
+// device between two kernels) and pseg_last_ms returns 0
+#define TIMED_RECORD(k) do { if (ctx->timing) HIPCHK(hipEventRecord(ctx->ev[k], ctx->cur)); } while (0)
+#define TIMED_ELAPSED(m, a, b) do { if (ctx->timing) HIPCHK(hipEventElapsedTime(&ctx->ms[m], ctx->ev[a], ctx->ev[b])); else ctx->ms[m] = 0; } while (0)
 static int ensure(pseg_ctx *ctx, DevBuf &b, size_t bytes)
 {
     if (bytes <= b.bytes) return 0;
@@ -232,6 +237,7 @@ extern "C" int pseg_create(int device, int H, int W, int max_frames, pseg_ctx **
     if (const char *e = getenv("PSEG_EARLY_RELEASE")) ctx->early_release = atoi(e) != 0;
     if (const char *e = getenv("PSEG_SHARED_STREAM")) ctx->shared_stream = atoi(e) != 0;
     if (const char *e = getenv("PSEG_RUNS_OLD")) ctx->runs_old = atoi(e) != 0;
+    if (const char *e = getenv("PSEG_TIMING")) ctx->timing = atoi(e) != 0;
     if (const char *e = getenv("PSEG_BAND_ORDER")) {
         const int v = atoi(e);
         ctx->band_order = v >= 0 && v <= 2 ? v : (v == 3 ? 1 : 0);
@@ -473,7 +479,7 @@ static int run_bg(pseg_ctx *ctx, const uint8_t *frames, int n_avail, int n_emit,
             ctx->bounds_tailk = tailk;
         }
     }
-    HIPCHK(hipEventRecord(ctx->ev[0], ctx->cur));
+    TIMED_RECORD(0);
     if (stream && P % 2048 == 0)
         hipLaunchKernelGGL(k_bg_stream<false>, dim3(nfull + (nblk - nfull) * tailk, chunks), dim3(256), 0, ctx->cur, frames, P, cleaned,
                            mask, thr, (uint8_t *)ctx->bits.p, (uint4 *)ctx->partials.p, (const int *)ctx->bounds.p, (uint8_t *)ctx->trash.p,
@@ -490,7 +496,6 @@ static int run_bg(pseg_ctx *ctx, const uint8_t *frames, int n_avail, int n_emit,
                                cleaned + f0 * P, mask, thr, (uint8_t *)ctx->bits.p + f0 * (P / 8), (uint32_t *)ctx->partials.p + f0 * npart * 4);
         }
     HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(ctx->ev[1], ctx->cur));
     hipLaunchKernelGGL(k_reduce_partials, dim3(n), dim3(1024), 0, ctx->cur, (const uint32_t *)ctx->partials.p, (int)npart,
                        (unsigned long long)P, (unsigned long long *)ctx->fsums.p, (uint8_t *)ctx->valid_dev.p, 1, 0, 4,
                        (unsigned long long *)ctx->maskcnt.p, (uint32_t *)ctx->framebase.p + n + 1,
@@ -498,6 +503,9 @@ static int run_bg(pseg_ctx *ctx, const uint8_t *frames, int n_avail, int n_emit,
                        (unsigned long long *)ctx->scan_state.p, scan_words(ctx, n));
     ctx->mask_counted = stream && mask;
     HIPCHK(hipGetLastError());
+    // one event ends the background group (the reduction of the raw sums belongs to it) and starts the labelling group: every
+    // event between two kernels of a stream showed as 6.5 us of idle device in the kernel trace
+    TIMED_RECORD(1);
     return 0;
 }
 
@@ -546,7 +554,7 @@ extern "C" int pseg_bgcorrect(pseg_ctx *ctx, const uint8_t *frames, int n, int n
     if (r) return r;
     r = fetch_raw_stats(ctx, n, mean_std, valid);
     if (r) return r;
-    HIPCHK(hipEventElapsedTime(&ctx->ms[0], ctx->ev[0], ctx->ev[1]));
+    TIMED_ELAPSED(0, 0, 1);
     return PSEG_OK;
 }
 
@@ -628,7 +636,7 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
     uint32_t *ftot = (uint32_t *)ctx->ftot.p;            // [n] run totals | [3n] rank totals | [n+1] rowbase | [n+1] savedbase
     uint32_t *ftot3 = ftot + n, *rowbase = ftot3 + 3 * (size_t)n, *savedbase = rowbase + (n + 1);
 
-    HIPCHK(hipEventRecord(ctx->ev[2], ctx->cur));
+    // (the labelling group is timed from ev[1], which run_bg / pseg_detect recorded behind the reduction kernel)
     // (the counters were cleared by k_reduce_partials; the mask pixels were counted by the background kernel when it ran fused)
     if (mask && !ctx->mask_counted)
         hipLaunchKernelGGL(k_mask_count, dim3(1024), dim3(256), 0, ctx->cur, mask, P, (unsigned long long *)ctx->maskcnt.p);
@@ -796,7 +804,7 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
         // (running the label fill on a second stream next to the crop / property kernels was measured: the fill takes 2.0 ms
         // instead of 0.93 ms when it shares the CUs, a net loss)
         if (labels) { int r_ = launch_fill(spec, nfg); if (r_) return r_; }
-        HIPCHK(hipEventRecord(ctx->ev[4], ctx->cur));
+        TIMED_RECORD(4);
         // The streaming kernels of this batch are queued.  What follows (crops, properties, hulls) waits on memory latency and
         // fills neither the vector units nor the memory system: the next batch's background kernel may run beside it.
         if (ctx->turn && ctx->early_release && !turn_released) { ctx->turn->release(); turn_released = true; }
@@ -872,7 +880,7 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
                                (const long long *)ctx->bits_off.p, (const int32_t *)ctx->maskbits.p, d_sums, hsmall, hmax);
         HIPCHK(hipGetLastError());
     }
-    HIPCHK(hipEventRecord(ctx->ev[5], ctx->cur));
+    TIMED_RECORD(5);
     ctx->crop_bytes = h_tot[0];
     ctx->n_saved = n_saved;
 
@@ -892,9 +900,9 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
     if (n_rows > 0) HIPCHK(hipMemcpyAsync(hp, ctx->outpack.p, o_bytes, hipMemcpyDeviceToHost, ctx->cur));
     HIPCHK(hipEventRecord(ctx->ev[8], ctx->cur));           // (an event, not the stream: other contexts' tails share it)
     HIPCHK(hipEventSynchronize(ctx->ev[8]));
-    HIPCHK(hipEventElapsedTime(&ctx->ms[2], ctx->ev[2], ctx->ev[3]));
-    HIPCHK(hipEventElapsedTime(&ctx->ms[3], ctx->ev[3], ctx->ev[4]));
-    HIPCHK(hipEventElapsedTime(&ctx->ms[4], ctx->ev[4], ctx->ev[5]));
+    TIMED_ELAPSED(2, 1, 3);
+    TIMED_ELAPSED(3, 3, 4);
+    TIMED_ELAPSED(4, 4, 5);
 
     int32_t *h_fro = ctx->h_frame_row_offset.as<int32_t>(n + 1);
     int32_t *h_fnc = ctx->h_frame_n_contours.as<int32_t>(n);
@@ -948,26 +956,26 @@ extern "C" int pseg_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t 
     ENSURE(ctx->partials, (size_t)n * nblk * 4 * sizeof(uint32_t));
     { int r_ = head_setup(ctx, n); if (r_) return r_; }
     GpuTurn turn(ctx);
-    HIPCHK(hipEventRecord(ctx->ev[6], ctx->cur));
+    TIMED_RECORD(6);
     if (valid) HIPCHK(hipMemcpyAsync(ctx->valid_dev.p, valid, n, hipMemcpyHostToDevice, ctx->cur));
     else HIPCHK(hipMemsetAsync(ctx->valid_dev.p, 1, n, ctx->cur));
-    HIPCHK(hipEventRecord(ctx->ev[0], ctx->cur));
+    TIMED_RECORD(0);
     hipLaunchKernelGGL(k_threshold, dim3(nblk, n), dim3(256), 0, ctx->cur, cleaned, P, mask, threshold, (uint8_t *)ctx->bits.p,
                        (uint32_t *)ctx->partials.p);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(ctx->ev[1], ctx->cur));
     hipLaunchKernelGGL(k_reduce_partials, dim3(n), dim3(1024), 0, ctx->cur, (const uint32_t *)ctx->partials.p, (int)nblk,
                        (unsigned long long)P, (unsigned long long *)ctx->fsums.p, (uint8_t *)ctx->valid_dev.p, 0, 2, 2,
                        (unsigned long long *)ctx->maskcnt.p, (uint32_t *)ctx->framebase.p + n + 1, (const uint32_t *)nullptr, 0,
                        (unsigned long long *)ctx->scan_state.p, scan_words(ctx, n));
     ctx->mask_counted = false;
     HIPCHK(hipGetLastError());
+    TIMED_RECORD(1);
     r = run_detect(ctx, cleaned, raw, mask, n, min_area_to_segment, min_area_to_save, labels, out);
     if (r) return r;
     HIPCHK(hipEventRecord(ctx->ev[7], ctx->cur));
     HIPCHK(hipEventSynchronize(ctx->ev[7]));
-    HIPCHK(hipEventElapsedTime(&ctx->ms[1], ctx->ev[0], ctx->ev[1]));
-    HIPCHK(hipEventElapsedTime(&ctx->ms[5], ctx->ev[6], ctx->ev[7]));
+    TIMED_ELAPSED(1, 0, 1);
+    TIMED_ELAPSED(5, 6, 7);
     ctx->ms[0] = 0;
     return PSEG_OK;
 }
@@ -982,7 +990,7 @@ static int process_impl(pseg_ctx *ctx, const uint8_t *frames, int n_avail, int n
     if (n_emit < 1 || n_emit > n_avail) return fail(ctx, PSEG_ERR_ARG, "n_emit out of range");
     const int n = n_emit;
     GpuTurn turn(ctx);
-    HIPCHK(hipEventRecord(ctx->ev[6], ctx->cur));
+    TIMED_RECORD(6);
     r = run_bg(ctx, frames, n_avail, n_emit, n_bg_imgs, mask, threshold, cleaned, batch_len);
     if (r) return r;
     r = run_detect(ctx, cleaned, cleaned, mask, n, min_area_to_segment, min_area_to_save, labels, out);
@@ -991,8 +999,8 @@ static int process_impl(pseg_ctx *ctx, const uint8_t *frames, int n_avail, int n
     r = fetch_raw_stats(ctx, n, mean_std, valid);
     if (r) return r;
     HIPCHK(hipEventSynchronize(ctx->ev[7]));
-    HIPCHK(hipEventElapsedTime(&ctx->ms[0], ctx->ev[0], ctx->ev[1]));
-    HIPCHK(hipEventElapsedTime(&ctx->ms[5], ctx->ev[6], ctx->ev[7]));
+    TIMED_ELAPSED(0, 0, 1);
+    TIMED_ELAPSED(5, 6, 7);
     ctx->ms[1] = 0;
     return PSEG_OK;
 }
