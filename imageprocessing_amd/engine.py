@@ -87,7 +87,9 @@ class Segmenter:
         h = C.c_void_p()
         rc = self.L.pseg_create(device, H, W, max_frames, C.byref(h))
         if rc != 0:
-            raise PsegError(f"pseg_create failed with code {rc} (no usable HIP device?)")
+            why = {-1: "bad geometry: 2 <= H <= 65535, W a multiple of 64 up to 8192, 1 <= max_frames <= 65535, "
+                       "max_frames * (H + 1) < 2^31", -2: "a HIP call failed", -4: "no usable HIP device"}.get(rc, "")
+            raise PsegError(f"pseg_create({device}, {H}, {W}, {max_frames}) failed with code {rc} ({why})")
         self.h = h
 
     def close(self):

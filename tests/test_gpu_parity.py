@@ -519,3 +519,93 @@ def test_known_answer_frames(gpu_seg_factory):
     assert len(tab.area[tab.frame == 2]) == 2
     dets = helpers.oracle_detect(items, None, min_area_to_segment=1, min_area_to_save=5, mask_img=False)
     assert sorted(r[6] for r in dets[0]["rows"]) == [2.0, 8.0, 10.0] and [r[6] for r in dets[1]["rows"]] == [441.0]
+
+
+def _structured_frame(rng, H, W):
+    """Foreground built from primitives that each stress one rule of the contour semantics: filled boxes and disks, box and
+    circle outlines (holes; nested ones: objects inside holes inside objects), one-pixel diagonals and staircases (8-connected
+    foreground, 4-connected background), spirals (long thin components with many band crossings), contacts with all four
+    frame borders, speckle, and erasures that open holes and pinch components."""
+    fg = np.zeros((H, W), bool)
+    yy, xx = np.mgrid[0:H, 0:W]
+    for _ in range(int(rng.integers(4, 14))):
+        kind = int(rng.integers(0, 8))
+        cy, cx = int(rng.integers(0, H)), int(rng.integers(0, W))
+        r = int(rng.integers(2, max(3, min(H, W) // 3)))
+        if kind == 0:                                       # filled box (may leave the frame: border contact)
+            fg[max(cy - r, 0):cy + r, max(cx - r // 2, 0):cx + r] = True
+        elif kind == 1:                                     # nested box outlines, 1 - 3 px thick, gap of 1 - 3 px
+            t, g = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+            k = r
+            while k > 0:
+                box = (np.abs(yy - cy) <= k) & (np.abs(xx - cx) <= k)
+                inner = (np.abs(yy - cy) <= k - t) & (np.abs(xx - cx) <= k - t)
+                fg |= box & ~inner
+                k -= t + g
+        elif kind == 2:                                     # disk
+            fg |= (yy - cy) ** 2 + (xx - cx) ** 2 <= r * r
+        elif kind == 3:                                     # circle outline (8-connected ring: its hole is 4-separated)
+            d2 = (yy - cy) ** 2 + (xx - cx) ** 2
+            fg |= (d2 <= r * r) & (d2 >= (r - 1.3) ** 2)
+        elif kind == 4:                                     # one-pixel diagonal, either direction
+            s = 1 if rng.random() < 0.5 else -1
+            for k in range(-r, r + 1):
+                y, x = cy + k, cx + s * k
+                if 0 <= y < H and 0 <= x < W:
+                    fg[y, x] = True
+        elif kind == 5:                                     # rectangular spiral, 1 px wide, pitch 2 or 3
+            p = int(rng.integers(2, 4))
+            y, x, dy, dx, leg = cy, cx, 0, 1, p
+            for turn in range(2 * r // p):
+                for _ in range(leg):
+                    if 0 <= y < H and 0 <= x < W:
+                        fg[y, x] = True
+                    y += dy; x += dx
+                dy, dx = dx, -dy
+                if turn % 2 == 1:
+                    leg += p
+        elif kind == 6:                                     # a bar along one of the frame borders
+            side = int(rng.integers(0, 4))
+            if side == 0: fg[0:int(rng.integers(1, 4)), cx:cx + 3 * r] = True
+            elif side == 1: fg[H - int(rng.integers(1, 4)):H, cx:cx + 3 * r] = True
+            elif side == 2: fg[cy:cy + 3 * r, 0:int(rng.integers(1, 4))] = True
+            else: fg[cy:cy + 3 * r, W - int(rng.integers(1, 4)):W] = True
+        else:                                               # speckle patch
+            y0, x0 = max(cy - r, 0), max(cx - r, 0)
+            patch = rng.random((min(2 * r, H - y0), min(2 * r, W - x0))) < rng.choice([0.15, 0.5, 0.8])
+            fg[y0:y0 + patch.shape[0], x0:x0 + patch.shape[1]] |= patch
+    for _ in range(int(rng.integers(0, 5))):                # erasures
+        cy, cx, r = int(rng.integers(0, H)), int(rng.integers(0, W)), int(rng.integers(1, 6))
+        if rng.random() < 0.5:
+            fg[max(cy - r, 0):cy + r, max(cx - 1, 0):cx + 1] = False
+        else:
+            fg[cy, max(cx - 3 * r, 0):cx + 3 * r] = False
+    return fg
+
+
+@pytest.mark.parametrize("H,W,seed", [(64, 64, 0), (65, 128, 1), (127, 128, 2), (128, 192, 3), (129, 64, 4), (200, 256, 5),
+                                      (63, 320, 6), (3, 128, 7), (2, 64, 8), (192, 128, 9)])
+def test_structured_shapes_sweep(H, W, seed):
+    """Seeded frames of nested outlines, spirals, diagonals, border contacts and speckle at frame heights on either side of
+    the 64-row band (2, 3, 63, 65, 127, 129 rows ...): table, crops, properties and label map equal the contour-tracing oracle,
+    with the area thresholds moved so that the kept / saved boundaries fall inside the population."""
+    import torch
+    from imageprocessing_amd.engine import Segmenter
+    rng = np.random.default_rng(1000 + seed)
+    n = 12
+    cleaned = np.full((n, H, W), 255, np.uint8)
+    for f in range(n):
+        fg = _structured_frame(rng, H, W)
+        vals = rng.integers(0, 244, size=(H, W), dtype=np.uint8)     # 255 - v > 10 for every v <= 244
+        cleaned[f][fg] = vals[fg]
+    seg = Segmenter(H, W, max_frames=n, device=0)
+    try:
+        for seg_min, save_min in [(2, 12), (10, 400)] if H >= 64 else [(1, 3)]:
+            items = [(cleaned[f], cleaned[f], [100.0, 50.0], f"s_{f:03d}.png") for f in range(n)]
+            dets = helpers.oracle_detect(items, None, min_area_to_segment=seg_min, min_area_to_save=save_min, mask_img=False)
+            labels = torch.empty((n, H, W), dtype=torch.int32, device="cuda")
+            tab = seg.detect(torch.from_numpy(cleaned).cuda(), min_area_to_segment=seg_min, min_area_to_save=save_min, labels=labels,
+                             fetch_crops=True)
+            helpers.compare_table(tab, dets, H, W, labels=labels.cpu().numpy())
+    finally:
+        seg.close()
