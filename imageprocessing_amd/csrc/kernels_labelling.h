@@ -439,6 +439,9 @@ __global__ __launch_bounds__(256) void k_runs_band(SegState S, int wpl, uint32_t
                     __builtin_amdgcn_s_sleep(2);
                     sv[k] = __hip_atomic_load(&scan[2 + idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
+#ifdef BAND_PROF
+                if (spins) { atomicAdd(&g_band_prof[9], (unsigned long long)spins); atomicAdd(&g_band_prof[10], 1ull); }   // polls, threads that polled
+#endif
                 if ((sv[k] >> 62) == 0) { timeout = true; sv[k] = SCAN_INC; }   // never expected; the host reports it
                 const unsigned long long incm = __ballot((sv[k] >> 62) == 2);
                 const int L = incm ? (int)__builtin_ctzll(incm) : 64;
@@ -446,6 +449,9 @@ __global__ __launch_bounds__(256) void k_runs_band(SegState S, int wpl, uint32_t
                 if (lane == 63) { lb_sum[4 * k + wv] = part_sum; lb_hit[4 * k + wv] = incm != 0; }
             }
             if (timeout) bandmax[1] = 1;
+#ifdef BAND_PROF
+            if (threadIdx.x == 0) atomicAdd(&g_band_prof[8], 1ull);                    // look-back rounds
+#endif
             __syncthreads();
             bool hit = false;
             for (int w = 0; w < 4 * LB_K && !hit; w++) { excl += lb_sum[w]; hit = lb_hit[w] != 0; }

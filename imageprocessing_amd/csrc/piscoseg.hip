@@ -263,7 +263,8 @@ extern "C" int pseg_destroy(pseg_ctx *ctx)
             fprintf(stderr, "k_runs_band phases, us per block over %llu blocks:", p[15]);
             const char *nm[6] = {"ticket", "load+count", "runs->LDS", "label", "look-back", "publish"};
             for (int k = 0; k < 6; k++) fprintf(stderr, " %s %.2f", nm[k], 0.01 * (double)p[k] / (double)p[15]);
-            fprintf(stderr, "\n");
+            fprintf(stderr, "; look-back rounds per block %.2f, threads that polled per block %.2f, polls per such thread %.1f\n",
+                    (double)p[8] / (double)p[15], (double)p[10] / (double)p[15], p[10] ? (double)p[9] / (double)p[10] : 0.0);
         }
     }
 #endif
