@@ -2,7 +2,7 @@
 """Turn the counter_collection.csv files of two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) into
 profiles/traffic.json: HBM bytes per launch of each kernel group, corrected as MI355X_MICROARCH.md (HBM) says:
 the CSV values are in kilobytes; gfx950 tallies 128-B read requests at 64 B, so reads are doubled; WRITE_SIZE is
-taken as is.  Groups are the ones bench.py times with HIP events (k_reduce_partials lies outside them).
+taken as is.  Groups are the ones bench.py times with HIP events (k_reduce_partials belongs to the background group since round 2's closing code).
 usage: pmc_to_traffic.py <fetch.csv> <write.csv> <out.json>"""
 import csv
 import json
@@ -11,9 +11,9 @@ from collections import defaultdict
 
 # kernel name prefix -> group (template arguments vary: k_bg_stream<false>, k_runs_band<10>, ...); everything else that starts
 # with k_ belongs to the sparse labelling chain
-PREFIX = [("k_bg_stream", "bg_correct"), ("k_bg_generic", "bg_correct"), ("k_label_fill", "label_map"),
+PREFIX = [("k_bg_stream", "bg_correct"), ("k_bg_generic", "bg_correct"), ("k_reduce_partials", "bg_correct"), ("k_label_fill", "label_map"),
           ("k_crops_sums", "crops_props"), ("k_convex", "crops_props"), ("k_band_map", "crops_props"), ("k_pack_out", "crops_props")]
-SKIP = ("k_synth", "k_fill_spans", "__amd", "k_reduce_partials", "k_mask_count")
+SKIP = ("k_synth", "k_fill_spans", "__amd", "k_mask_count")
 
 
 def group_of(kernel):
