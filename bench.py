@@ -370,6 +370,10 @@ def main():
                  "frac_of_hbm_peak_per_gpu": round(fps / world * path_bytes / (HBM_PEAK_GBS * 1e9), 4),
                  "frac_of_hbm_peak_per_gpu_with_objects": round(fps / world * (path_bytes + obj_bytes) / (HBM_PEAK_GBS * 1e9), 4),
                  "contexts": ns, "driver": args.driver, "results_checked_after_timed_region": checked,
+                 # the band kernel's scan order of the contexts after the run (1: block index, 0: tickets) and how often one of them
+                 # had to give the index order up (a timed-out scan: the batch is repeated inside the call)
+                 "band_scan_order": [s_.tuning_state()["band_order"] for s_ in segs],
+                 "band_scan_fallbacks": sum(s_.tuning_state()["band_order_fallbacks"] for s_ in segs),
                  "ranks_seen": dist.get_world_size() if dist_on else 1,
                  "halo_overhead": round(halo, 4) if strong else 0.0,
                  "table_gather_messages_per_step": n_gather if dist_on else None,
