@@ -24,6 +24,16 @@
 #ifndef CROP_LDS_WORDS
 #define CROP_LDS_WORDS 2048          // mask words of a band + 2 halo rows on each side (frames up to 8192 px wide: 8 rows of 256 words)
 #endif
+#define CROP_SMALL_ONE (1ull << 40)   // the band column of the size scan: bands | small windows << 40
+#ifndef CROP_SMALL_THREADS
+#define CROP_SMALL_THREADS 64
+#endif
+#ifndef CROP_SMALL_TPR
+#define CROP_SMALL_TPR 2
+#endif
+#define CROP_SMALL_WORDS 256          // LDS words per array of the small class: (124 + 4) rows x 2 words
+// a window of one band whose mask rows (+ 4 halo rows) fit CROP_SMALL_WORDS
+__host__ __device__ inline bool crop_band_is_small(int w, int h) { return w <= 64 && h <= 124; }
 __host__ __device__ inline int crop_rows_per_band(int w)
 {
     int r = CROP_BAND / w;
@@ -78,7 +88,9 @@ __global__ void k_emit(SegState S, uint32_t cap, uint32_t bcap, double min_seg, 
         const int rpb = crop_rows_per_band(w);
         sz[sidx] = (unsigned long long)w * h;
         sz[szstride + sidx] = (unsigned long long)h;
-        sz[2 * szstride + sidx] = (unsigned long long)((h + rpb - 1) / rpb);
+        // (bit 40 counts the windows of the small class of k_crops_sums, which have one band: the scan of this column then gives
+        // every object its bands' place among the bands of its own class -- k_band_map)
+        sz[2 * szstride + sidx] = (unsigned long long)((h + rpb - 1) / rpb) | (crop_band_is_small(w, h) ? CROP_SMALL_ONE : 0ull);
     }
 }
 
@@ -262,7 +274,14 @@ __global__ __launch_bounds__(256) void k_band_map(int n_saved, const long long *
     if (s >= n_saved) return;
     if (lane < PSEG_NSUMS) sums[(size_t)s * PSEG_NSUMS + lane] = lane == 6 ? 255 : 0;   // min intensity starts at 255
     const int4 g0 = *(const int4 *)(geo + 8 * (size_t)s), g1 = *(const int4 *)(geo + 8 * (size_t)s + 4);
-    const long long b0 = band_off[s], b1 = band_off[s + 1], co = crop_off[s], ro = row_off[s];
+    // descriptors of the small class first (one per small window, in object order), then the bands of the other objects:
+    // small windows before s = high part of the scanned column, bands before s = low part
+    const unsigned long long p0 = (unsigned long long)band_off[s], p1 = (unsigned long long)band_off[s + 1];
+    const long long n_small = (long long)((unsigned long long)band_off[n_saved] >> 40);
+    const long long sm0 = (long long)(p0 >> 40), nb = (long long)((p1 & (CROP_SMALL_ONE - 1)) - (p0 & (CROP_SMALL_ONE - 1)));
+    const bool small = (p1 >> 40) != (p0 >> 40);
+    const long long b0 = small ? sm0 : n_small + (long long)(p0 & (CROP_SMALL_ONE - 1)) - sm0, b1 = b0 + nb;
+    const long long co = crop_off[s], ro = row_off[s];
     const int rpb = crop_rows_per_band(g0.w);
     for (long long b = b0 + lane; b < b1; b += 64) {
         int4 *d = (int4 *)(band_desc + BAND_DESC_INTS * (size_t)b);
@@ -295,18 +314,25 @@ __device__ __forceinline__ void divmod_small(int p, int d, float rcp, int &q, in
     r = p - (int)__umul24((uint32_t)q, (uint32_t)d);
     if (r < 0) { q--; r += d; } else if (r >= d) { q++; r -= d; }
 }
-template <bool DENSE>
-__global__ __launch_bounds__(CROP_THREADS) void k_crops_sums(SegState S, int n_saved, const int32_t *__restrict__ geo,
+// Size classes: THREADS / TPR (threads that share a row while painting) / LW (words of each LDS array).  <256, 4, LW>
+// serves every band; <64, 2, CROP_SMALL_WORDS> serves the single-band windows of small objects (crop_band_is_small: up to 64
+// columns and 124 rows), of which a CU then holds 32 at a time instead of 8 -- on frames of 2000 objects the kernel is a chain of
+// latencies per object, and what shortens it is the number of objects in flight.  The fused path launches one grid per class
+// over its own stretch of the descriptors (k_band_map puts the small windows first; grids over all bands with the other
+// class's blocks returning at once cost 0.15 ms per 100 000 bands).  cls: 0 = every band, 1 = small windows, 2 = the others
+// (a guard only: a block whose band is of the other class returns).
+template <bool DENSE, int THREADS, int TPR, int LW>
+__global__ __launch_bounds__(THREADS) void k_crops_sums(SegState S, int n_saved, const int32_t *__restrict__ geo,
                                                     const long long *__restrict__ crop_off, const long long *__restrict__ band_off,
                                                     const int32_t *__restrict__ objflag, const uint8_t *__restrict__ cleaned,
                                                     const uint8_t *__restrict__ raw, uint8_t *__restrict__ c_raw,
                                                     uint8_t *__restrict__ c_masked, uint8_t *__restrict__ c_mask, long long *sums,
                                                     const long long *__restrict__ row_off, int32_t *__restrict__ rowext,
                                                     const int32_t *__restrict__ band_obj, const uint8_t *__restrict__ dense_mask,
-                                                    const int32_t *__restrict__ band_desc)
+                                                    const int32_t *__restrict__ band_desc, int cls)
 {
-    __shared__ uint32_t mbuf[CROP_LDS_WORDS];             // mask bits of rows r0-2 .. r1+1 (zero outside the window)
-    __shared__ uint32_t bd[CROP_LDS_WORDS];               // 4-neighbour border bits of rows r0-1 .. r1
+    __shared__ uint32_t mbuf[LW];             // mask bits of rows r0-2 .. r1+1 (zero outside the window)
+    __shared__ uint32_t bd[LW];               // 4-neighbour border bits of rows r0-1 .. r1
     __shared__ uint32_t acc[32];                          // block totals (see the end of the kernel)
     const long long bid = blockIdx.x;
     int s, f, bx, by, w, h, root, wpr, r0;
@@ -323,17 +349,18 @@ __global__ __launch_bounds__(CROP_THREADS) void k_crops_sums(SegState S, int n_s
         r0 = (int)(bid - band_off[s]) * crop_rows_per_band(w);
         coff = crop_off[s]; roff = row_off[s];
     }
+    if (cls != 0 && (cls == 1) != crop_band_is_small(w, h)) return;       // (block-uniform)
     const int rpb = crop_rows_per_band(w);
     const int r1 = (r0 + rpb < h) ? r0 + rpb : h;
     const int nrows = r1 - r0;
     const float rcp_wpr = 1.0f / (float)wpr, rcp_wpr1 = 1.0f / (float)(wpr + 1);
-    for (int wi = threadIdx.x; wi < (nrows + 4) * wpr; wi += CROP_THREADS) mbuf[wi] = 0;
+    for (int wi = threadIdx.x; wi < (nrows + 4) * wpr; wi += THREADS) mbuf[wi] = 0;
     if (threadIdx.x < 32) acc[threadIdx.x] = threadIdx.x == 15 ? 255u : 0u;    // acc[15] = running minimum
     __syncthreads();
     if (CROP_EXP & 2) {
     } else if (DENSE) {
         // pseg_regionprops: the mask is a dense uint8 image (nonzero = set) of row stride S.W instead of the run tables
-        for (int wi = threadIdx.x; wi < (nrows + 4) * wpr; wi += CROP_THREADS) {
+        for (int wi = threadIdx.x; wi < (nrows + 4) * wpr; wi += THREADS) {
             const int yl = wi / wpr, wx = wi - yl * wpr, yy = r0 - 2 + yl;
             uint32_t v = 0;
             if (yy >= 0 && yy < h) {
@@ -344,9 +371,9 @@ __global__ __launch_bounds__(CROP_THREADS) void k_crops_sums(SegState S, int n_s
             mbuf[wi] = v;
         }
     } else {
-        // CROP_TPR threads per row walk the row's runs; a run paints itself and the gap on its left when the object that fills
+        // TPR threads per row walk the row's runs; a run paints itself and the gap on its left when the object that fills
         // them (ext / gapl) is saved and was iterated at or before this one.  Two dependent global loads per row.
-        const int sub = threadIdx.x & (CROP_TPR - 1), x_lo = bx, x_hi = bx + w - 1;
+        const int sub = threadIdx.x & (TPR - 1), x_lo = bx, x_hi = bx + w - 1;
         auto paint = [&](uint32_t *mrow, int xa, int xb) {
             int la = (xa > x_lo ? xa : x_lo) - bx, lb = (xb < x_hi ? xb : x_hi) - bx;
             for (int wd = la >> 5; wd <= (lb >> 5); wd++) {
@@ -355,7 +382,7 @@ __global__ __launch_bounds__(CROP_THREADS) void k_crops_sums(SegState S, int n_s
                 atomicOr(&mrow[wd], m);
             }
         };
-        for (int yl = threadIdx.x / CROP_TPR; yl < nrows + 4; yl += CROP_THREADS / CROP_TPR) {
+        for (int yl = threadIdx.x / TPR; yl < nrows + 4; yl += THREADS / TPR) {
             const int yy = r0 - 2 + yl;
             if (yy < 0 || yy >= h) continue;
             const int rs = seg_rowstart(S, f, by + yy), n = seg_rowcount(S, f, by + yy);
@@ -364,11 +391,11 @@ __global__ __launch_bounds__(CROP_THREADS) void k_crops_sums(SegState S, int n_s
             // together -- one memory latency per round -- and only the runs that meet the window (one or two of a dense
             // frame's twenty per row) go on to the dependent loads: object of the run / of the gap on its left, saved flag.
             // (One run per step with all its loads took 0.39 of the kernel's 0.75 ms on frames of 2000 objects.)
-            for (int jb = 0; jb < n; jb += CROP_RPT * CROP_TPR) {
+            for (int jb = 0; jb < n; jb += CROP_RPT * TPR) {
                 uint32_t rx[CROP_RPT], px[CROP_RPT];
 #pragma unroll
                 for (int k = 0; k < CROP_RPT; k++) {
-                    const int j = jb + k * CROP_TPR + sub;
+                    const int j = jb + k * TPR + sub;
                     rx[k] = j < n ? S.run_x[rs + j] : 0xffffu;                   // past the row's runs: xs = 65535, xe = 0
                     px[k] = (j > 0 && j < n) ? S.run_x[rs + j - 1] : ((uint32_t)x_hi << 16);   // j == 0: the leading gap belongs to no object
                 }
@@ -379,7 +406,7 @@ __global__ __launch_bounds__(CROP_THREADS) void k_crops_sums(SegState S, int n_s
                     const bool run_in = xe >= x_lo && xs <= x_hi, gap_in = xs - 1 >= x_lo && pe + 1 <= x_hi;
                     xs_last = xs;
                     if (run_in || gap_in) {
-                        const int r = rs + jb + k * CROP_TPR + sub;
+                        const int r = rs + jb + k * TPR + sub;
                         const int idr = S.ext[r], idg = S.gapl[r];
                         // (the object itself is saved by definition: the flag is only looked up for other objects inside the window)
                         if (run_in && (idr == root || (idr > root && (objflag[idr] & 2)))) paint(mrow, xs, xe);
@@ -393,7 +420,7 @@ __global__ __launch_bounds__(CROP_THREADS) void k_crops_sums(SegState S, int n_s
     __syncthreads();
     // border = mask minus its erosion by the 4-neighbour cross, zero outside the window
     // (skimage perimeter(image, 4): binary_erosion(..., border_value=0), _regionprops_utils.py:225-231)
-    for (int wi = threadIdx.x; wi < (nrows + 2) * wpr; wi += CROP_THREADS) {
+    for (int wi = threadIdx.x; wi < (nrows + 2) * wpr; wi += THREADS) {
         int yl, wx;                                        // row r0-1+yl  ->  mbuf row yl+1
         divmod_small(wi, wpr, rcp_wpr, yl, wx);
         const uint32_t *m = mbuf + __umul24((uint32_t)(yl + 1), (uint32_t)wpr);
@@ -418,7 +445,7 @@ __global__ __launch_bounds__(CROP_THREADS) void k_crops_sums(SegState S, int n_s
         const int cpr = (w + 15) >> 4, nitem = nrows * cpr;
         const float rcp = 1.0f / (float)cpr;
 #pragma unroll CROP_UNROLL
-        for (int p = threadIdx.x; p < nitem; p += CROP_THREADS) {
+        for (int p = threadIdx.x; p < nitem; p += THREADS) {
             int yl = (int)((float)p * rcp);
             int c = p - (int)__umul24((uint32_t)yl, (uint32_t)cpr);
             if (c < 0) { yl--; c += cpr; } else if (c >= cpr) { yl++; c -= cpr; }
@@ -457,7 +484,7 @@ __global__ __launch_bounds__(CROP_THREADS) void k_crops_sums(SegState S, int n_s
         const int cpr = (w + 7) >> 3, nitem = nrows * cpr;
         const float rcp = 1.0f / (float)cpr;
 #pragma unroll CROP_UNROLL
-        for (int p = threadIdx.x; p < nitem; p += CROP_THREADS) {
+        for (int p = threadIdx.x; p < nitem; p += THREADS) {
             int yl = (int)((float)p * rcp);
             int c = p - (int)__umul24((uint32_t)yl, (uint32_t)cpr);
             if (c < 0) { yl--; c += cpr; } else if (c >= cpr) { yl++; c -= cpr; }
@@ -496,7 +523,7 @@ __global__ __launch_bounds__(CROP_THREADS) void k_crops_sums(SegState S, int n_s
         const int cpr = (w + 3) >> 2, nitem = nrows * cpr;
         const float rcp = 1.0f / (float)cpr;
 #pragma unroll CROP_UNROLL
-        for (int p = threadIdx.x; p < nitem; p += CROP_THREADS) {
+        for (int p = threadIdx.x; p < nitem; p += THREADS) {
             // (products of values below 2^24 go through v_mul_u32_u24: the full 32-bit multiply runs at a quarter of the rate)
             int yl = (int)((float)p * rcp);               // p / cpr, corrected below (p < 2^24)
             int c = p - (int)__umul24((uint32_t)yl, (uint32_t)cpr);
@@ -523,7 +550,7 @@ __global__ __launch_bounds__(CROP_THREADS) void k_crops_sums(SegState S, int n_s
             mn_e = pkmin(mn_e, __builtin_amdgcn_perm(0, out4, 0x0c020c00)); mn_o = pkmin(mn_o, __builtin_amdgcn_perm(0, out4, 0x0c030c01));
         }
     } else {                                              // windows narrower than a dword: thread per pixel
-        for (int p = threadIdx.x; p < nrows * w; p += CROP_THREADS) {
+        for (int p = threadIdx.x; p < nrows * w; p += THREADS) {
             const int yl = p / w, xx = p - yl * w;
             const uint32_t bit = (mb[yl * wpr] >> xx) & 1u;
             const uint32_t cv = sb[(size_t)yl * S.W + xx];
@@ -547,7 +574,7 @@ __global__ __launch_bounds__(CROP_THREADS) void k_crops_sums(SegState S, int n_s
     //           [[10,2,10],[2,1,2],[10,2,10]] over the border image is 1 + 2*n4 + 10*nd; n4 / nd are counted with bit-sliced adders
     uint32_t mo[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // n, wx n, wx^2 n, sk, wx sk, sk2, yl n, yl^2 n, yl wx n, yl sk
     uint32_t pc1 = 0, pc2 = 0, pc3 = 0;
-    for (int wi = threadIdx.x; wi < ((CROP_EXP & 8) ? 0 : nrows * wpr); wi += CROP_THREADS) {
+    for (int wi = threadIdx.x; wi < ((CROP_EXP & 8) ? 0 : nrows * wpr); wi += THREADS) {
         int yl_, wx_;
         divmod_small(wi, wpr, rcp_wpr, yl_, wx_);
         const uint32_t yl = (uint32_t)yl_, wx = (uint32_t)wx_;
@@ -596,7 +623,7 @@ __global__ __launch_bounds__(CROP_THREADS) void k_crops_sums(SegState S, int n_s
     int eul = 0;
     {
         const int ylast = (r1 == h) ? nrows + 1 : nrows;   // the last band also owns the quads below the window
-        for (int wi = threadIdx.x; wi < ((CROP_EXP & 8) ? 0 : ylast * (wpr + 1)); wi += CROP_THREADS) {
+        for (int wi = threadIdx.x; wi < ((CROP_EXP & 8) ? 0 : ylast * (wpr + 1)); wi += THREADS) {
             int yl, wx;
             divmod_small(wi, wpr + 1, rcp_wpr1, yl, wx);
             const uint32_t *B = mbuf + __umul24((uint32_t)(yl + 2), (uint32_t)wpr), *T = B - wpr;     // bottom row r0+yl, top row r0+yl-1
@@ -606,7 +633,7 @@ __global__ __launch_bounds__(CROP_THREADS) void k_crops_sums(SegState S, int n_s
         }
     }
     // first / last set column of every row of the band (input of the convex hull kernel)
-    for (int yl = threadIdx.x; yl < nrows; yl += CROP_THREADS) {
+    for (int yl = threadIdx.x; yl < nrows; yl += THREADS) {
         const uint32_t *m = mb + yl * wpr;
         int first = 0x7fffffff, last = -1;
         for (int wx = 0; wx < wpr; wx++) if (m[wx]) { first = 32 * wx + __ffs(m[wx]) - 1; break; }
@@ -638,20 +665,28 @@ __global__ __launch_bounds__(CROP_THREADS) void k_crops_sums(SegState S, int n_s
     if (threadIdx.x == 0 && !(CROP_EXP & 1)) {
         unsigned long long *q = (unsigned long long *)(sums + (size_t)s * PSEG_NSUMS);
         const unsigned long long N = acc[0], R0 = (unsigned long long)r0;
-        if (N) {
+        if (r0 == 0 && r1 == h) {
+            // the window's only band: plain stores (k_band_map has set the start values; q[9] and q[14] belong to others)
+            q[0] = N; q[1] = acc[6]; q[2] = 32ull * acc[1] + acc[3]; q[3] = acc[7];
+            q[4] = 1024ull * acc[2] + 64ull * acc[4] + acc[5]; q[5] = 32ull * acc[8] + acc[9];
+            q[6] = acc[15]; q[7] = acc[16]; q[8] = acc[10];
+            q[10] = acc[11]; q[11] = acc[12]; q[12] = acc[13]; q[13] = (unsigned long long)(long long)(int)acc[14];
+        } else if (N) {
             const unsigned long long sx = 32ull * acc[1] + acc[3];                                    // sum c
             const unsigned long long sx2 = 1024ull * acc[2] + 64ull * acc[4] + acc[5];                // sum c^2
             const unsigned long long sy = acc[6], sy2 = acc[7], syx = 32ull * acc[8] + acc[9];        // band-local rows
             atomicAdd(&q[0], N); atomicAdd(&q[1], R0 * N + sy); atomicAdd(&q[2], sx);
             atomicAdd(&q[3], R0 * R0 * N + 2ull * R0 * sy + sy2); atomicAdd(&q[4], sx2); atomicAdd(&q[5], R0 * sx + syx);
         }
-        if (acc[10]) atomicAdd(&q[8], (unsigned long long)acc[10]);
-        if (acc[15] < 255u) atomicMin((long long *)&q[6], (long long)acc[15]);
-        if (acc[16] > 0u) atomicMax((long long *)&q[7], (long long)acc[16]);
-        if (acc[11]) atomicAdd(&q[10], (unsigned long long)acc[11]);
-        if (acc[12]) atomicAdd(&q[11], (unsigned long long)acc[12]);
-        if (acc[13]) atomicAdd(&q[12], (unsigned long long)acc[13]);
-        if (acc[14]) atomicAdd(&q[13], (unsigned long long)(long long)(int)acc[14]);
+        if (!(r0 == 0 && r1 == h)) {
+            if (acc[10]) atomicAdd(&q[8], (unsigned long long)acc[10]);
+            if (acc[15] < 255u) atomicMin((long long *)&q[6], (long long)acc[15]);
+            if (acc[16] > 0u) atomicMax((long long *)&q[7], (long long)acc[16]);
+            if (acc[11]) atomicAdd(&q[10], (unsigned long long)acc[11]);
+            if (acc[12]) atomicAdd(&q[11], (unsigned long long)acc[12]);
+            if (acc[13]) atomicAdd(&q[12], (unsigned long long)acc[13]);
+            if (acc[14]) atomicAdd(&q[13], (unsigned long long)(long long)(int)acc[14]);
+        }
     }
 }
 

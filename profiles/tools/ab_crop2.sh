@@ -1,0 +1,10 @@
+#!/bin/bash
+# crop kernel variants, kernel statistics only (dense workload, then the headline workload)
+cd $GRAFT_REPO_ROOT
+for v in "$@"; do
+  if [ "$v" = base ]; then unset PSEG_LIB; else export PSEG_LIB=$GRAFT_REPO_ROOT/variants/libpiscoseg_$v.so; fi
+  for wl in uvp5_dense_saved pisco; do
+    echo "== $v $wl"
+    timeout -k 10 250 bash profiles/tools/kstats.sh abc_${v}_$wl --workload $wl | grep -i "crops_sums" || exit 1
+  done
+done
