@@ -869,9 +869,10 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
                    (const long long *)ctx->bits_off.p, (int32_t *)ctx->maskbits.p, (const int32_t *)nullptr, (const uint8_t *)nullptr,          \
                    (const int32_t *)ctx->band_obj.p + BAND_DESC_INTS * (size_t)(first)
         // two size classes: the descriptors of the small windows come first (k_band_map); PSEG_CROP_CLASSES=0: one class for all
-        // (the small class only where it carries a good part of the batch: with a few hundred small windows among large ones the
-        // second launch costs more than the windows gain -- 0.195 against 0.173 ms on the headline workload)
-        if (ctx->crop_classes && n_small >= 2048 && 4 * n_small >= n_bands) {
+        // (the small class only where it carries most of the batch: with a quarter of small windows among large ones -- the
+        // headline workload -- the two launches take 0.195 against 0.173 ms alone, and beside the next batch's background kernel
+        // the large class then ran 0.31 instead of 0.22 ms)
+        if (ctx->crop_classes && n_small >= 2048 && 2 * n_small >= n_bands) {
             if (n_small > 0)
                 hipLaunchKernelGGL((k_crops_sums<false, CROP_SMALL_THREADS, CROP_SMALL_TPR, CROP_SMALL_WORDS>), dim3((unsigned)n_small), dim3(CROP_SMALL_THREADS), 0, ctx->cur, CROPS_ARGS(0), 1);
             if (n_bands > n_small)
