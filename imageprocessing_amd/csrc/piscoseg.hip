@@ -16,6 +16,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <chrono>
 #include <string>
 #include <vector>
 #include <mutex>
@@ -916,6 +917,9 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
     if (n_rows > 0) HIPCHK(hipMemcpyAsync(hp, ctx->outpack.p, o_bytes, hipMemcpyDeviceToHost, ctx->cur));
     HIPCHK(hipEventRecord(ctx->ev[8], ctx->cur));           // (an event, not the stream: other contexts' tails share it)
     HIPCHK(hipEventSynchronize(ctx->ev[8]));
+#ifdef HOST_PROF
+    const auto hp_t0 = std::chrono::steady_clock::now();
+#endif
     TIMED_ELAPSED(2, 1, 3);
     TIMED_ELAPSED(3, 3, 4);
     TIMED_ELAPSED(4, 4, 5);
@@ -942,6 +946,9 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
         const int i = h_saved_row[s];
         props_from_sums(h_sums + (size_t)s * PSEG_NSUMS, hrows[6 * hr + i], hrows[7 * hr + i], h_props + (size_t)s * PSEG_NPROPS);
     }
+#ifdef HOST_PROF
+    fprintf(stderr, "host epilogue %.1f us (%d rows, %d saved)\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - hp_t0).count(), n_rows, n_saved);
+#endif
     ctx->t_rows = hrows; ctx->t_saved_row = h_saved_row; ctx->t_crop_off = h_crop_off; ctx->t_hr = hr;
     if (out) {
         memset(out, 0, sizeof(*out));
