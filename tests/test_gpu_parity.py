@@ -609,3 +609,40 @@ def test_structured_shapes_sweep(H, W, seed):
             helpers.compare_table(tab, dets, H, W, labels=labels.cpu().numpy())
     finally:
         seg.close()
+
+
+def test_properties_of_symmetric_windows():
+    """Windows whose mixed central moment is exactly zero (rectangles either way up, a square, a cross, a disk): the angle
+    column then hangs on the SIGN of that zero (atan2(-0, x < 0) = -pi, atan2(+0, x < 0) = +pi: 0 or 180 degrees), and the
+    elongation / eccentricity of the square on exact equality of the two eigenvalues.  The fused path computes the
+    columns on the device, the single-window entry point on the host: both must give the oracle's values."""
+    import torch
+    from imageprocessing_amd.engine import Segmenter
+    H, W = 256, 512
+    fg = np.zeros((H, W), bool)
+    fg[20:50, 30:80] = True                                  # 30 x 50
+    fg[20:70, 130:160] = True                                # 50 x 30
+    fg[100:140, 30:70] = True                                # square
+    fg[110:130, 200:280] = True; fg[90:150, 230:250] = True  # cross
+    yy, xx = np.mgrid[0:H, 0:W]
+    fg |= (yy - 190) ** 2 + (xx - 400) ** 2 <= 35 * 35       # disk
+    fg[180:200, 60:61] = True; fg[180:200, 64:65] = True     # two thin bars (areas below the thresholds)
+    cleaned = np.full((1, H, W), 255, np.uint8)
+    cleaned[0][fg] = 100
+    items = [(cleaned[0], cleaned[0], [100.0, 50.0], "sym_000.png")]
+    dets = helpers.oracle_detect(items, None, min_area_to_segment=10, min_area_to_save=400, mask_img=False)
+    seg = Segmenter(H, W, max_frames=1, device=0)
+    try:
+        labels = torch.empty((1, H, W), dtype=torch.int32, device="cuda")
+        tab = seg.detect(torch.from_numpy(cleaned).cuda(), labels=labels, fetch_crops=True)
+        assert tab.saved.sum() == 5
+        helpers.compare_table(tab, dets, H, W, labels=labels.cpu().numpy())
+        # the same windows through pseg_regionprops (host epilogue): identical columns, bit for bit except the angle's last place
+        for s in range(len(tab.saved_row)):
+            i = int(tab.saved_row[s])
+            m = torch.from_numpy(np.ascontiguousarray(tab.crop(s, "mask"))).cuda()
+            g = torch.from_numpy(np.ascontiguousarray(tab.crop(s, "masked"))).cuda()
+            one = seg.regionprops(m, g)
+            np.testing.assert_allclose(one[4:], tab.saved_props[s][4:], rtol=1e-12, atol=1e-12, equal_nan=True)
+    finally:
+        seg.close()
