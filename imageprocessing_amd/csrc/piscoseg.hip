@@ -98,7 +98,7 @@ struct pseg_ctx {
                                   // 256-pixel span, -1 (default) = by the density of the previous batch
     bool dense_rows = false;      // the last batch had FILL_ROWS_MIN or more runs per row on average
     // host results
-    HostBuf h_frame_row_offset, h_frame_n_contours, h_frame_valid, h_frame_mean, h_frame_std, h_area, h_saved8, h_props;
+    HostBuf h_frame_row_offset, h_frame_n_contours, h_frame_valid, h_frame_mean, h_frame_std, h_area, h_saved8;
     int64_t crop_bytes = 0;
     int n_saved = 0;
     // host views of the last table (page-locked tail buffer): rows [10][t_hr], saved_row, crop_off
