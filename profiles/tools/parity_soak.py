@@ -1,6 +1,9 @@
 """One-off parity soak (not part of the test suite): seeded structured frames (tests/test_gpu_parity._structured_frame) and noise
 frames at many geometries, every batch through pseg_detect and against the contour-tracing oracle with tests/helpers.compare_table
-(bit-exact table, crops, label map; float columns to 1e-5).  usage: parity_soak.py <first seed> <number of seeds>"""
+(bit-exact table, crops, label map; float columns to 1e-5).  usage: parity_soak.py <first seed> <number of seeds>
+Mode "bg": parity_soak.py bg <first seed> <number of seeds> -- the fused call (background correction + detection) on random stacks
+of 12 - 90 frames (smooth fields + noise + a few flat frames that fail the std > 2 gate), random time chunks and pretended block
+slots, against oracle correct_img / detect_on_img: cleaned frames bit for bit, raw and masked mean / std, validity, full tables."""
 import sys, time
 import numpy as np
 sys.path.insert(0, '.')
@@ -9,6 +12,57 @@ from tests import helpers
 from tests.test_gpu_parity import _structured_frame
 from imageprocessing_amd.engine import Segmenter
 
+def soak_bg(first, count):
+    import os
+    t0 = time.time()
+    frames = rows = 0
+    for seed in range(first, first + count):
+        rng = np.random.default_rng(91000 + seed)
+        H, W = [(64, 128), (96, 192), (128, 256), (80, 64), (200, 320)][seed % 5]
+        n = int(rng.integers(12, 91))
+        os.environ["PSEG_BG_CHUNKS"] = str(int(rng.integers(1, 5)))
+        if seed % 3 == 0:
+            os.environ["PSEG_BG_TAIL"] = str(int(rng.integers(2, 9)))
+        else:
+            os.environ.pop("PSEG_BG_TAIL", None)
+        base = rng.integers(120, 230)
+        yy, xx = np.mgrid[0:H, 0:W]
+        stack = np.empty((n, H, W), np.uint8)
+        for f in range(n):
+            field = base + 20 * np.sin(xx / 37.0 + f / 5.0) + 10 * np.cos(yy / 23.0)
+            img = field + rng.normal(0, 6, (H, W))
+            for _ in range(int(rng.integers(0, 5))):          # dark particles
+                cy, cx, r = rng.integers(0, H), rng.integers(0, W), rng.integers(2, 14)
+                img[(yy - cy) ** 2 + (xx - cx) ** 2 <= r * r] -= rng.integers(40, 120)
+            stack[f] = np.clip(img, 0, 255).astype(np.uint8)
+        for f in rng.integers(0, n, int(rng.integers(0, 3))):
+            stack[f] = rng.integers(0, 256)                   # flat frame: std = 0 -> invalid
+        mask = helpers.make_disk(H, W, min(H, W) // 2 - 3)
+        items = helpers.oracle_bgcorrect(stack)
+        dets = helpers.oracle_detect(items, mask, min_area_to_segment=3, min_area_to_save=30)
+        seg = Segmenter(H, W, max_frames=n, device=0)
+        try:
+            labels = torch.empty((n, H, W), dtype=torch.int32, device="cuda")
+            cleaned, ms, valid, tab = seg.process(torch.from_numpy(stack).cuda(), mask=torch.from_numpy(mask).cuda(), labels=labels,
+                                                  min_area_to_segment=3, min_area_to_save=30, fetch_crops=True)
+            cl = cleaned.cpu().numpy()
+            for i, it in enumerate(items):
+                np.testing.assert_allclose(ms[i], it[2], rtol=1e-9, atol=1e-9)
+                assert valid[i] == (0 if isinstance(it[1], list) else 1)
+                if valid[i]:
+                    assert np.array_equal(cl[i], it[1]), f"seed {seed} frame {i}"
+            helpers.compare_table(tab, dets, H, W, labels=labels.cpu().numpy())
+        finally:
+            seg.close()
+        frames += n; rows += tab.n_rows
+        if (seed - first) % 20 == 19:
+            print(f"bg seed {seed}: {frames} frames, {rows} rows equal to the oracle, {time.time() - t0:.0f} s", flush=True)
+    print(f"parity soak (background correction + detection): seeds {first}..{first + count - 1}: {frames} frames, {rows} rows -- all equal to the oracle ({time.time() - t0:.0f} s)")
+
+
+if sys.argv[1] == "bg":
+    soak_bg(int(sys.argv[2]), int(sys.argv[3]))
+    sys.exit(0)
 first, count = int(sys.argv[1]), int(sys.argv[2])
 sizes = [(64, 64), (100, 128), (191, 256), (256, 512), (320, 192), (65, 1024), (512, 512), (130, 2560)]
 t0 = time.time()
