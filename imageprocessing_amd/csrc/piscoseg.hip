@@ -76,12 +76,14 @@ struct pseg_ctx {
     DevBuf rows, saved_row, saved_geo, crop_off, bits_off, maskbits, crops_raw, crops_masked, crops_mask;
     bool mask_counted = false;    // maskcnt already holds the number of mask == 255 pixels (fused background kernel)
     bool have_bits = false;       // threshold plane + masked sums already produced by the bg kernel
+    DevBuf scan_part;             // chunk totals of the size scan (k_scan_sizes_part)
     DevBuf bounds, band_off, band_obj /* one 64-byte descriptor per crop band: k_band_map */, trash, rp_small, rp_scratch, resize_tab, synth_objs, synth_off;
     int bounds_n = -1, bounds_emit = -1, bounds_chunks = -1, bounds_batch = -1;
     int band_order = 1;           // k_runs_band's scan order: 1 = block index (BAND_ORDER_INDEX; falls back to 0 = tickets for good when
                                   // a scan times out), 2 = raise the timeout flag once (test of the fallback); PSEG_BAND_ORDER
     int band_test_call = -1, detect_calls = 0;   // PSEG_BAND_ORDER=3: index order, and mode 2 on the context's third batch (a queued chain)
     int band_fallbacks = 0;       // times the index order was given up (pseg_tuning_state)
+    int scan_multi_min = 16384;   // (SCAN_MULTI_MIN of kernels_output.h) PSEG_SCAN_MULTI_MIN: saved objects of the previous batch from which the size scan takes two launches
     bool crop_classes = true;     // PSEG_CROP_CLASSES=0: one size class of k_crops_sums for every band
     bool timing = true;           // PSEG_TIMING=0: no timing events in the stream
     bool runs_old = false;        // PSEG_RUNS_OLD=1: two-pass run extraction (k_runs) + k_band_label instead of the fused k_runs_band
@@ -241,6 +243,7 @@ extern "C" int pseg_create(int device, int H, int W, int max_frames, pseg_ctx **
     if (const char *e = getenv("PSEG_RUNS_OLD")) ctx->runs_old = atoi(e) != 0;
     if (const char *e = getenv("PSEG_TIMING")) ctx->timing = atoi(e) != 0;
     if (const char *e = getenv("PSEG_CROP_CLASSES")) ctx->crop_classes = atoi(e) != 0;
+    if (const char *e = getenv("PSEG_SCAN_MULTI_MIN")) ctx->scan_multi_min = atoi(e);
     if (const char *e = getenv("PSEG_BAND_ORDER")) {
         const int v = atoi(e);
         ctx->band_order = v >= 0 && v <= 2 ? v : (v == 3 ? 1 : 0);
@@ -276,7 +279,7 @@ extern "C" int pseg_destroy(pseg_ctx *ctx)
                       &ctx->bg_parent, &ctx->bg_left, &ctx->minx, &ctx->maxx, &ctx->maxy, &ctx->area2,
                       &ctx->extrank, &ctx->keptrank, &ctx->savedrank, &ctx->objlabel, &ctx->objflag, &ctx->rows,
                       &ctx->saved_row, &ctx->saved_geo, &ctx->crop_off, &ctx->bits_off, &ctx->maskbits,
-                      &ctx->crops_raw, &ctx->crops_masked, &ctx->crops_mask, &ctx->bounds, &ctx->band_off, &ctx->band_obj, &ctx->trash, &ctx->rp_small, &ctx->rp_scratch, &ctx->resize_tab,
+                      &ctx->crops_raw, &ctx->crops_masked, &ctx->crops_mask, &ctx->bounds, &ctx->band_off, &ctx->band_obj, &ctx->scan_part, &ctx->trash, &ctx->rp_small, &ctx->rp_scratch, &ctx->resize_tab,
                       &ctx->synth_objs, &ctx->synth_off};
     for (DevBuf *b : bufs) if (b->p) hipFree(b->p);
     for (PinBuf *b : {&ctx->pin_head, &ctx->pin_tail, &ctx->pin_nfg}) if (b->p) hipHostFree(b->p);
@@ -682,6 +685,7 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
         ENSURE(ctx->saved_row, cap * 4);
         ENSURE(ctx->saved_geo, cap * 8 * 4 + 3 * sz_stride(cap) * 8);
         ENSURE(ctx->crop_off, (cap + 1) * 8); ENSURE(ctx->bits_off, (cap + 1) * 8); ENSURE(ctx->band_off, (cap + 1) * 8);
+        ENSURE(ctx->scan_part, (size_t)SCAN_BLOCKS * 4 * 8);
         S.run_x = (uint32_t *)ctx->run_x.p; S.run_fy = (uint32_t *)ctx->run_fy.p;
         S.fg_parent = (int32_t *)ctx->fg_parent.p; S.ext = (int32_t *)ctx->ext.p; S.gapl = (int32_t *)ctx->gapl.p;
         S.bg_parent = (int32_t *)ctx->bg_parent.p; S.bg_left = (int32_t *)ctx->bg_left.p;
@@ -727,9 +731,13 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
             hipLaunchKernelGGL(k_emit, dim3(nblocks(runs)), dim3(256), 0, ctx->cur, S, capv, bcap, min_seg, min_save, (const uint32_t *)ftot3,
                                (const uint32_t *)rowbase, (const uint32_t *)savedbase, R, objlabel, objflag, saved_row,
                                (int32_t *)ctx->runlabel.p, geo, sz, sz_stride(rcap));
-        hipLaunchKernelGGL(k_scan_sizes, dim3(1), dim3(1024), 0, ctx->cur, S, capv, bcap, (const unsigned long long *)sz, sz_stride(rcap),
+        const int scan_blocks = ctx->n_saved > ctx->scan_multi_min ? SCAN_BLOCKS : 1;      // (by the previous batch)
+        if (scan_blocks > 1)
+            hipLaunchKernelGGL(k_scan_sizes_part, dim3(scan_blocks), dim3(1024), 0, ctx->cur, S, capv, bcap, (const unsigned long long *)sz, sz_stride(rcap),
+                               (const uint32_t *)(savedbase + n), (unsigned long long *)ctx->scan_part.p);
+        hipLaunchKernelGGL(k_scan_sizes, dim3(scan_blocks), dim3(1024), 0, ctx->cur, S, capv, bcap, (const unsigned long long *)sz, sz_stride(rcap),
                            (const uint32_t *)(savedbase + n), (long long *)ctx->crop_off.p, (long long *)ctx->bits_off.p,
-                           (long long *)ctx->band_off.p, totals);
+                           (long long *)ctx->band_off.p, totals, (const unsigned long long *)ctx->scan_part.p);
     };
     auto launch_fill = [&](bool spec_, int nfg_) -> int {
         // one wave per row where rows hold many runs (FILL_ROWS_MIN per row on average: 1.0 ms against 1.7 ms at 19 runs per

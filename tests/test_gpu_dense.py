@@ -200,3 +200,37 @@ def test_band_scan_order_and_its_fallback(monkeypatch, order):
         assert st["band_order_fallbacks"] == (1 if order in "23" else 0)
     finally:
         seg.close()
+
+
+def test_size_scan_in_two_launches(monkeypatch):
+    """The scan of the saved objects' sizes (crop offsets, row offsets, bands) takes one block, or SCAN_BLOCKS blocks in two launches
+    where the previous batch saved many objects; PSEG_SCAN_MULTI_MIN=-1 sends every batch down the second way (also the first,
+    and batches that save nothing or fewer objects than there are blocks): tables, crops and label maps equal the oracle."""
+    import torch
+    from imageprocessing_amd.engine import Segmenter
+    monkeypatch.setenv("PSEG_SCAN_MULTI_MIN", "-1")
+    H, W, n = 256, 512, 6
+    rng = np.random.default_rng(31)
+    seg = Segmenter(H, W, max_frames=n, device=0)
+
+    def run(cleaned, save_min):
+        items = [(cleaned[f], cleaned[f], [100.0, 50.0], f"z_{f:03d}.png") for f in range(n)]
+        dets = helpers.oracle_detect(items, None, min_area_to_segment=2, min_area_to_save=save_min, mask_img=False)
+        labels = torch.empty((n, H, W), dtype=torch.int32, device="cuda")
+        tab = seg.detect(torch.from_numpy(cleaned).cuda(), min_area_to_segment=2, min_area_to_save=save_min, labels=labels, fetch_crops=True)
+        helpers.compare_table(tab, dets, H, W, labels=labels.cpu().numpy())
+        return int(tab.saved.sum())
+
+    try:
+        empty = np.full((n, H, W), 255, np.uint8)
+        assert run(empty, 30) == 0                           # nothing at all
+        few = empty.copy()
+        few[2, 40:80, 50:120] = 90; few[4, 100:130, 300:360] = 50
+        assert run(few, 30) == 2                             # fewer objects than blocks
+        many = empty.copy()
+        for f in range(n):
+            many[f][rng.random((H, W)) < 0.3] = 120
+        assert run(many, 4) > 1500                           # every block has its chunk (also one that is not a multiple of 8)
+        assert run(many, 12) > 100
+    finally:
+        seg.close()
