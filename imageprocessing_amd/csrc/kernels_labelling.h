@@ -258,11 +258,16 @@ __global__ __launch_bounds__(256) void k_band_label(SegState S)
 // XCD's slots have smaller indices and wait for nothing unfinished) -- how the hardware dispatches a 1-D grid, but not a
 // documented promise, so it is not trusted: the spin bound is short in this mode, and the host answers the timeout flag by
 // running the batch again with tickets and keeping them for the rest of the context's life (no wrong result, no hang).
+// It also needs this kernel to be the only one of its kind on the device: two index-ordered scans side by side can hold each
+// other's slots (A's late blocks fill the XCD that B's earliest unfinished block is waiting to be placed on, and the other way
+// round) until the bound ends it.  Inside one process the per-device turn guarantees that; contexts that do not take turns
+// (PSEG_EXCLUSIVE=0) start with tickets, and processes that share a GPU find out through the timeout -- seen once in a
+// rehearsal with four processes on one GPU (profiles/r02/56), which is why the bound is as short as it is.
 // BAND_ORDER_TEST raises the timeout flag without waiting (the host's way back is under test in tests/test_gpu_async.py).
 #define SCAN_AGG (1ull << 62)
 #define SCAN_INC (2ull << 62)
 #define SCAN_SPIN_MAX (1 << 22)
-#define SCAN_SPIN_MAX_INDEX (1 << 18)
+#define SCAN_SPIN_MAX_INDEX (1 << 16)
 #define BAND_ORDER_TICKET 0
 #define BAND_ORDER_INDEX 1
 #define BAND_ORDER_TEST 2

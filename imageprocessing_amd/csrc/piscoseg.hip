@@ -244,6 +244,7 @@ extern "C" int pseg_create(int device, int H, int W, int max_frames, pseg_ctx **
     if (const char *e = getenv("PSEG_TIMING")) ctx->timing = atoi(e) != 0;
     if (const char *e = getenv("PSEG_CROP_CLASSES")) ctx->crop_classes = atoi(e) != 0;
     if (const char *e = getenv("PSEG_SCAN_MULTI_MIN")) ctx->scan_multi_min = atoi(e);
+    if (!ctx->exclusive) ctx->band_order = 0;                // no turns: two band kernels may share the device (see BAND_ORDER_INDEX)
     if (const char *e = getenv("PSEG_BAND_ORDER")) {
         const int v = atoi(e);
         ctx->band_order = v >= 0 && v <= 2 ? v : (v == 3 ? 1 : 0);
@@ -702,9 +703,12 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
         sz = (unsigned long long *)(geo + 8 * rcap);
         return 0;
     };
+    bool turn_released = false;
     auto launch_fused = [&](uint32_t capv) {
+        // (a batch that is repeated after its turn was handed on may meet another context's band kernel on the device: tickets)
+        const int band_order = (turn_released && ctx->band_order == 1) ? 0 : ctx->band_order;
         const dim3 g(nbpf * n), b(256);
-#define BAND_LAUNCH(WPL_, CAP_) hipLaunchKernelGGL((k_runs_band<WPL_, CAP_>), g, b, 0, ctx->cur, S, runs_wpl, capv, scan, bandmax_d, ctx->band_order)
+#define BAND_LAUNCH(WPL_, CAP_) hipLaunchKernelGGL((k_runs_band<WPL_, CAP_>), g, b, 0, ctx->cur, S, runs_wpl, capv, scan, bandmax_d, band_order)
         if (runs_wpl > 10) {
             if (ctx->band_cap > BAND_CAP_MID) BAND_LAUNCH(16, BAND_CAP_DENSE);
             else if (ctx->band_cap > BAND_CAP) BAND_LAUNCH(16, BAND_CAP_MID);
@@ -767,7 +771,6 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
     if (ctx->detect_calls++ == ctx->band_test_call && ctx->band_order == 1) ctx->band_order = 2;
     bool spec = fused && !ctx->no_bands && ctx->runcap > 0 && ctx->spec_hold == 0;
     if (ctx->spec_hold > 0) ctx->spec_hold--;
-    bool turn_released = false;
     int nfg = 0;
     uint32_t band_seen = 0;
     for (;;) {

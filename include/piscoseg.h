@@ -199,7 +199,9 @@ float pseg_last_ms(const pseg_ctx *ctx, int which);
  * even for the largest class), 3 = 1 when the next label map is written row-wise (dense rows), 0 span-wise,
  * 4 = order of the band kernel's look-back scan (1 = block index, the default; 0 = tickets from an atomic counter, which
  * a context moves to for good after a scan in index order timed out -- the batch is repeated inside the call; environment
- * PSEG_BAND_ORDER=0 starts there), 5 = times that has happened.
+ * PSEG_BAND_ORDER=0 starts there, and so do contexts that take no turns, PSEG_EXCLUSIVE=0; several processes sharing one GPU
+ * should set it: their band kernels can block each other in index order until the bound, about 0.1 s, ends it),
+ * 5 = times that has happened.
  * Returns -1 for a bad argument. */
 long long pseg_tuning_state(const pseg_ctx *ctx, int which);
 
