@@ -234,3 +234,28 @@ def test_size_scan_in_two_launches(monkeypatch):
         assert run(many, 12) > 100
     finally:
         seg.close()
+
+
+def test_contexts_without_turns_scan_with_tickets(monkeypatch):
+    """Index order needs the band kernel to be alone of its kind on the device, which only the per-device turn guarantees: a
+    context created with PSEG_EXCLUSIVE=0 starts with tickets (and an explicit PSEG_BAND_ORDER still wins)."""
+    from imageprocessing_amd.engine import Segmenter
+    monkeypatch.setenv("PSEG_EXCLUSIVE", "0")
+    seg = Segmenter(128, 128, max_frames=2, device=0)
+    try:
+        assert seg.tuning_state()["band_order"] == 0
+    finally:
+        seg.close()
+    monkeypatch.setenv("PSEG_BAND_ORDER", "1")
+    seg = Segmenter(128, 128, max_frames=2, device=0)
+    try:
+        assert seg.tuning_state()["band_order"] == 1
+    finally:
+        seg.close()
+    monkeypatch.delenv("PSEG_EXCLUSIVE")
+    monkeypatch.delenv("PSEG_BAND_ORDER")
+    seg = Segmenter(128, 128, max_frames=2, device=0)
+    try:
+        assert seg.tuning_state()["band_order"] == 1
+    finally:
+        seg.close()
