@@ -780,6 +780,9 @@ __global__ __launch_bounds__(THREADS) void k_crops_sums(SegState S, int n_saved,
 // Dynamic LDS: 56 bytes per row of the tallest object served by the launch (the host launches one size class per
 // call so that small objects keep a high occupancy).
 #define HULL_LDS_PER_ROW 28
+#ifndef HULL_EXP
+#define HULL_EXP 0                   // experiments only (wrong results): 1 no chains at all, 2 no merge rounds, 4 no vertex array / row bounds
+#endif
 typedef short hull_t;                // profile values (|X| <= 2 * 8191 + 1, sentinels +-20000) and list links (< 2 * 2700 + 2) fit 16 bits
 template <bool LOWER>
 __device__ __forceinline__ bool hull_drop(int ra, int va, int rb, int vb, int rc, int vc)   // b is no strict vertex between a and c
@@ -814,7 +817,7 @@ __device__ __forceinline__ void hull_chain(const hull_t *pv, int np, volatile hu
             nxt[top] = -1;
         }
     }
-    for (int s = 1; s < 64; s <<= 1) {                      // merge the hulls of lanes [l, l+s) and [l+s, l+2s)
+    for (int s = 1; s < ((HULL_EXP & 2) ? 0 : 64); s <<= 1) {   // merge the hulls of lanes [l, l+s) and [l+s, l+2s)
         hull_wave_sync();
         const int vstart = (lane + s) * seg;
         if ((lane & (2 * s - 1)) == 0 && vstart < np) {
@@ -831,6 +834,7 @@ __device__ __forceinline__ void hull_chain(const hull_t *pv, int np, volatile hu
         }
     }
     hull_wave_sync();
+    if (HULL_EXP & 4) return;
     hull_t *vl = (hull_t *)prv;                             // vertex array over the (now dead) back links: vl[k] sits at or before vertex k
     int nv = 0;
     if (lane == 0) for (int i = 0; i >= 0; i = nxt[i]) vl[nv++] = (hull_t)i;
@@ -881,8 +885,10 @@ __global__ __launch_bounds__(128) void k_convex(int n_saved, const int32_t *__re
         pvl[i] = (hull_t)l; pvu[i] = (hull_t)u;
     }
     __syncthreads();
+    if (!(HULL_EXP & 1)) {
     if (threadIdx.x < 64) hull_chain<true>(pvl, np, nxl, prl, fl, h, threadIdx.x);
     else hull_chain<false>(pvu, np, nxu, pru, fl, h, threadIdx.x - 64);
+    }
     __syncthreads();
     unsigned long long cnt = 0;
     for (int r = threadIdx.x; r < h; r += 128)
