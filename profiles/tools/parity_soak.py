@@ -1,6 +1,9 @@
 """One-off parity soak (not part of the test suite): seeded structured frames (tests/test_gpu_parity._structured_frame) and noise
 frames at many geometries, every batch through pseg_detect and against the contour-tracing oracle with tests/helpers.compare_table
 (bit-exact table, crops, label map; float columns to 1e-5).  usage: parity_soak.py <first seed> <number of seeds>
+Mode "parts": parity_soak.py parts <first seed> <number of seeds> -- stacks of 30 - 520 frames cut into frame ranges for 2 - 8 ranks
+(sharding.plan_ranges, pseg_process_part with forward halos) against the same stacks in whole reference batches (200 frames, the
+last one 200 - 399): cleaned frames, label maps, statistics and merged tables identical.
 Mode "bg": parity_soak.py bg <first seed> <number of seeds> -- the fused call (background correction + detection) on random stacks
 of 12 - 90 frames (smooth fields + noise + a few flat frames that fail the std > 2 gate), random time chunks and pretended block
 slots, against oracle correct_img / detect_on_img: cleaned frames bit for bit, raw and masked mean / std, validity, full tables."""
@@ -60,6 +63,67 @@ def soak_bg(first, count):
     print(f"parity soak (background correction + detection): seeds {first}..{first + count - 1}: {frames} frames, {rows} rows -- all equal to the oracle ({time.time() - t0:.0f} s)")
 
 
+def soak_parts(first, count):
+    """frame-range sharding (sharding.plan_ranges + pseg_process_part with forward halos) against whole reference batches"""
+    from imageprocessing_amd import sharding
+    t0 = time.time()
+    frames = nparts = 0
+    for seed in range(first, first + count):
+        rng = np.random.default_rng(123000 + seed)
+        H, W = [(64, 128), (96, 192), (80, 64)][seed % 3]
+        n = int(rng.integers(30, 521))
+        yy, xx = np.mgrid[0:H, 0:W]
+        stack = np.empty((n, H, W), np.uint8)
+        base = rng.integers(120, 230)
+        for f in range(n):
+            img = base + 20 * np.sin(xx / 37.0 + f / 5.0) + 10 * np.cos(yy / 23.0) + rng.normal(0, 6, (H, W))
+            for _ in range(int(rng.integers(0, 5))):
+                cy, cx, r = rng.integers(0, H), rng.integers(0, W), rng.integers(2, 14)
+                img[(yy - cy) ** 2 + (xx - cx) ** 2 <= r * r] -= rng.integers(40, 120)
+            stack[f] = np.clip(img, 0, 255).astype(np.uint8)
+        for f in rng.integers(0, n, int(rng.integers(0, 4))):
+            stack[f] = rng.integers(0, 256)
+        mask = torch.from_numpy(helpers.make_disk(H, W, min(H, W) // 2 - 3)).cuda()
+        dev = torch.from_numpy(stack).cuda()
+        seg = Segmenter(H, W, max_frames=420, device=0)
+        try:
+            cleaned = torch.empty((n, H, W), dtype=torch.uint8, device="cuda")
+            labels = torch.empty((n, H, W), dtype=torch.int32, device="cuda")
+            ms = np.zeros((n, 2)); valid = np.zeros(n, np.uint8)
+            blobs = []
+            for a, m in sharding.batches_of(n):
+                c, q, v, tab = seg.process(dev[a:a + m], mask=mask, labels=labels[a:a + m], cleaned=cleaned[a:a + m], min_area_to_segment=3, min_area_to_save=30)
+                ms[a:a + m] = q; valid[a:a + m] = v
+                blobs.append(sharding.pack_table(tab, frame_base=a))
+            ref = sharding.merge_tables([sharding.unpack_table(b) for b in blobs])
+            world = int(rng.integers(2, 9))
+            blobs = []
+            for parts in sharding.plan_ranges(n, world):
+                for p in parts:
+                    s_, ne, na = p["start"], p["n_emit"], p["n_avail"]
+                    lab = torch.empty((ne, H, W), dtype=torch.int32, device="cuda")
+                    c, q, v, tab = seg.process(dev[s_:s_ + na], mask=mask, labels=lab, min_area_to_segment=3, min_area_to_save=30, n_emit=None if ne == na else ne)
+                    ok = torch.from_numpy(v.astype(bool)).cuda()
+                    assert torch.equal(c[ok], cleaned[s_:s_ + ne][ok]), f"seed {seed} part at {s_}: cleaned"
+                    assert torch.equal(lab, labels[s_:s_ + ne]), f"seed {seed} part at {s_}: labels"
+                    np.testing.assert_array_equal(q, ms[s_:s_ + ne]); np.testing.assert_array_equal(v, valid[s_:s_ + ne])
+                    blobs.append(sharding.pack_table(tab, frame_base=s_))
+                    nparts += 1
+            got = sharding.merge_tables([sharding.unpack_table(b) for b in blobs])
+            for k in ref:
+                if k != "shard_of_saved":
+                    np.testing.assert_array_equal(got[k], ref[k], err_msg=f"seed {seed} world {world}: {k}")
+        finally:
+            seg.close()
+        frames += n
+        if (seed - first) % 20 == 19:
+            print(f"parts seed {seed}: {frames} frames in {nparts} parts equal to the whole batches, {time.time() - t0:.0f} s", flush=True)
+    print(f"parity soak (frame ranges with halos against whole batches): seeds {first}..{first + count - 1}: {frames} frames, {nparts} parts over 2 - 8 ranks -- all equal ({time.time() - t0:.0f} s)")
+
+
+if sys.argv[1] == "parts":
+    soak_parts(int(sys.argv[2]), int(sys.argv[3]))
+    sys.exit(0)
 if sys.argv[1] == "bg":
     soak_bg(int(sys.argv[2]), int(sys.argv[3]))
     sys.exit(0)
