@@ -11,6 +11,12 @@ label map -> crops + property sums) over the whole stack of the configuration, r
           tables are gathered to rank 0 over RCCL inside the timed region.  The total work is fixed: "scaling": "strong".
           --scaling weak: every rank runs its own 2000-frame stack (whole batches, no halo).
 
+`python3 bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N rank processes itself (children of
+this process, started before anything here touches torch or the GPU; rank r uses GPU r) and relays rank 0's line; under
+`python -m torch.distributed.run` (WORLD_SIZE set) every process is a rank.  Either way the run fails when the ranks that
+took part are not --gpus.  --plan-only: process group, frame-range plan and the table gathers with empty tables, no kernels
+(what the CPU test of the launcher runs).
+
 A single caller thread keeps --streams contexts in flight with pseg_submit / pseg_wait (--driver threads: one host thread
 per context, the round-1 form).
 
@@ -49,6 +55,110 @@ def group_bytes_per_frame(name, rows_pf, crop_bytes_pf, labels_on):
     return 4 * crop_bytes_pf + 44 * 8 * rows_pf      # crops: one read + three planes written; the rows of the table
 
 
+def launch_ranks(n):
+    """--gpus n without a launcher: start the n ranks as child processes, one GPU each, and relay rank 0's JSON line.
+    Nothing in this process has imported torch or touched the GPU (children are plain subprocesses, never an exec of a
+    process that holds the device).  Exit status non-zero when a rank fails or the line does not report n ranks."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PSEG_BENCH_LAUNCH="self-spawned")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    failed = None
+    live = set(range(n))
+    while live and failed is None:
+        time.sleep(0.05)                                     # (rank 0 writes one short line into its pipe: it cannot fill up)
+        for r in sorted(live):
+            rc = procs[r].poll()
+            if rc is not None:
+                live.discard(r)
+                if rc != 0:
+                    failed = (r, rc)
+                    break
+    if failed is not None:
+        for r in live:
+            procs[r].terminate()                             # exactly the processes started above
+        for r in live:
+            try:
+                procs[r].wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                procs[r].kill()
+        sys.stderr.write(f"bench: rank {failed[0]} exited with status {failed[1]}\n")
+        return 1
+    text = procs[0].stdout.read().decode()
+    lines = [ln for ln in text.splitlines() if ln.strip().startswith("{")]
+    if not lines:
+        sys.stderr.write("bench: rank 0 printed no result line\n")
+        return 1
+    out = json.loads(lines[-1])
+    seen = out.get("ranks_seen", out.get("path", {}).get("ranks_seen"))
+    if out.get("n_gpus") != n or seen != n:
+        sys.stderr.write(f"bench: --gpus {n} but the line reports n_gpus {out.get('n_gpus')}, ranks_seen {seen}\n")
+        return 2
+    print(lines[-1], flush=True)
+    return 0
+
+
+class _EmptyTable:
+    """an object table of n frames without objects (--plan-only)"""
+    def __init__(self, n):
+        z32, z64, z8 = np.zeros(0, np.int32), np.zeros(0, np.float64), np.zeros(0, np.uint8)
+        self.n_frames, self.crop_bytes = n, 0
+        self.frame_row_offset = np.zeros(n + 1, np.int32)
+        self.frame_n_contours = np.zeros(n, np.int32)
+        self.frame_valid = np.ones(n, np.uint8)
+        self.frame_mean, self.frame_std = np.zeros(n), np.zeros(n)
+        self.frame = self.c = self.label = self.x = self.y = self.w = self.h = self.saved_row = z32
+        self.area, self.saved = z64, z8
+        self.saved_props = np.zeros((0, 32))
+        self.crop_offset = np.zeros(1, np.int64)
+
+
+def plan_only(args, world, rank, launch):
+    """process group + frame-range plan + the gather messages of one pass with empty tables: no kernels, no GPU"""
+    import torch.distributed as dist
+    from imageprocessing_amd import sharding
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    os.environ.setdefault("RANK", "0")
+    os.environ.setdefault("WORLD_SIZE", "1")
+    dist.init_process_group("gloo")
+    total_frames = args.frames or 10000
+    plan = sharding.plan_ranges(total_frames, world, window=2 * args.n_bg_imgs)
+    parts = plan[rank]
+    n_gather = max(max((len(p) + GATHER_EVERY - 1) // GATHER_EVERY for p in plan), 1)
+    gat = sharding.TableGatherer()
+    got = []
+    for g in range(n_gather):
+        mine = parts[(g * len(parts)) // n_gather:((g + 1) * len(parts)) // n_gather]
+        blobs = [sharding.pack_table(_EmptyTable(p["n_emit"]), frame_base=p["start"]) for p in mine]
+        res = gat.gather(np.concatenate(blobs) if blobs else np.zeros(8, np.uint8))
+        if rank == 0:
+            for blob in res:
+                if blob.size > 8:
+                    got += [sharding.unpack_table(b) for b in sharding.split_tables(blob)]
+    line = None
+    if rank == 0:
+        merged = sharding.merge_tables(got)
+        emitted = [sum(p["n_emit"] for p in pp) for pp in plan]
+        loaded = [sum(p["n_avail"] for p in pp) for pp in plan]
+        line = {"plan_only": True, "n_gpus": args.gpus, "ranks_seen": dist.get_world_size(), "launch": launch,
+                "frames": total_frames, "frames_merged": int(len(merged["frame_row_offset"]) - 1),
+                "frames_per_rank": emitted, "halo_frames_per_rank": [a - b for a, b in zip(loaded, emitted)],
+                "parts_per_rank": [len(pp) for pp in plan], "table_gather_messages_per_step": n_gather}
+    dist.barrier()
+    dist.destroy_process_group()
+    return line
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -70,7 +180,23 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="run the N > 1 code path (frame ranges, process group, table gathers on "
                     "their thread) with a world of one rank: all a one-GPU box allows through RCCL")
     ap.add_argument("--host-batches", type=int, default=6, help="batches of the host-input measurement (0 = skip)")
+    ap.add_argument("--plan-only", action="store_true", help="process group + frame-range plan + gathers of empty tables over gloo; "
+                    "no kernels, no GPU (the launcher's CPU test)")
+    ap.add_argument("--n-bg-imgs", type=int, default=6, help="half the background window (bg_correction.py:65; reference: 6)")
     args = ap.parse_args()
+
+    if args.gpus < 1:
+        raise SystemExit("bench: --gpus must be at least 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))                    # before torch is imported: this process never touches a GPU
+    launch = os.environ.get("PSEG_BENCH_LAUNCH") or ("torch.distributed.run" if "WORLD_SIZE" in os.environ else "single process")
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        raise SystemExit(f"bench: --gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE')}: the ranks that run must be --gpus")
+    if args.plan_only:
+        line = plan_only(args, int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), launch)
+        if line is not None:
+            print(json.dumps(line), flush=True)
+        return
 
     import torch
     import torch.distributed as dist
@@ -110,7 +236,7 @@ def main():
     # ---- the rank's frames and its library calls (start, n_emit, n_avail): whole batches, or parts with forward halos ----
     if strong:
         seed = 3
-        parts = sharding.plan_ranges(total_frames, world)[rank]
+        parts = sharding.plan_ranges(total_frames, world, window=2 * args.n_bg_imgs)[rank]
         g0 = parts[0]["start"] if parts else 0
         g1 = max((p["start"] + p["n_avail"] for p in parts), default=0)
         calls = [(p["start"] - g0, p["n_emit"], p["n_avail"], p["start"]) for p in parts]
@@ -139,7 +265,7 @@ def main():
     def kwargs(c, k):
         a, ne, na, _ = calls[c]
         return dict(mask=mask, cleaned=cleaned[k][:ne], labels=None if labels[k] is None else labels[k][:ne],
-                    n_emit=None if ne == na else ne)
+                    n_emit=None if ne == na else ne, n_bg_imgs=args.n_bg_imgs)
 
     def account(c, k, tab, timed):
         if timed:
@@ -158,7 +284,7 @@ def main():
     import queue as _queue
     import threading as _threading
     if strong:
-        n_gather = max(max((len(p) + GATHER_EVERY - 1) // GATHER_EVERY for p in sharding.plan_ranges(total_frames, world)), 1)
+        n_gather = max(max((len(p) + GATHER_EVERY - 1) // GATHER_EVERY for p in sharding.plan_ranges(total_frames, world, window=2 * args.n_bg_imgs)), 1)
     else:
         n_gather = max((len(calls) + GATHER_EVERY - 1) // GATHER_EVERY, 1)
     nc_ = len(calls)
@@ -195,7 +321,13 @@ def main():
                 return
             if self.buf is None:
                 self.buf = free_wires.get()
+            need = sharding.packed_bytes(tab)
+            if self.fill + need > self.buf.size:           # a dense table (256 B of properties per saved object): a larger wire
+                grown = np.empty(max(2 * self.buf.size, self.fill + need), np.uint8)
+                grown[:self.fill] = self.buf[:self.fill]
+                self.buf = grown                           # (returns to free_wires in place of the small one)
             self.fill += sharding.pack_table(tab, frame_base=calls[c][3], out=self.buf[self.fill:]).size
+            assert self.fill <= self.buf.size
             while self.g < n_gather and c + 1 >= group_end[self.g]:          # (also sends the empty messages of a rank with few parts)
                 gq.put((self.buf, self.fill, timed))
                 self.g += 1
@@ -300,7 +432,8 @@ def main():
         a, ne, na, _ = calls[0]
         want_c = torch.empty((ne, H, W), dtype=torch.uint8, device=dev)
         want_l = torch.empty((ne, H, W), dtype=torch.int32, device=dev) if labels_on else None
-        _, ms0, v0, t0_ = segs[0].process(stack[a:a + na], mask=mask, cleaned=want_c, labels=want_l, n_emit=None if ne == na else ne)
+        _, ms0, v0, t0_ = segs[0].process(stack[a:a + na], mask=mask, cleaned=want_c, labels=want_l, n_emit=None if ne == na else ne,
+                                          n_bg_imgs=args.n_bg_imgs)
         for k in GROUP_NAMES:
             iso_ms[k] = segs[0].last_ms(k)
         ref = {f: np.array(getattr(t0_, f)) for f in ("frame_row_offset", "frame_n_contours", "frame_mean", "frame_std", "c", "label",
@@ -355,26 +488,30 @@ def main():
         wl = (f"configs[{idx}]: {total_frames}-frame {args.workload} stack{' per GPU' if world > 1 else ''}, batches of {BATCH}")
     out = {
         "metric": "frames/sec (2560x2560 uint8), hot path bg_correction+detection",
-        "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": round(fps, 2), "unit": "frames/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 3), "higher_is_better": True,
         "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "config": {"workload": wl + f", bg window 12, ~{cfg['per_frame']} objects/frame, label map {'on' if labels_on else 'off'}",
+        "config": {"workload": wl + f", bg window {2 * args.n_bg_imgs}, ~{cfg['per_frame']} objects/frame, label map {'on' if labels_on else 'off'}",
                    "frames_per_step": total_frames if strong else total_frames * world,
                    "library_calls_per_step_rank0": len(calls), "objects_per_frame": round(stats["contours"] / fr, 1),
                    "rows_per_frame": round(rows_pf, 1), "saved_per_frame": round(stats["saved"] / fr, 1)},
         "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": dom["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": dom["frac"], "traffic": dom["counter_bytes"], "avg_launch_ms": dom["avg_ms"],
+                     "frac": dom["frac"], "traffic": dom["counter_bytes"],
+                     "traffic_source": None if dom["counter_bytes"] is None else "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
+                                       "of this code kept from the build session (profiles/README.md), scaled to this launch's frames; "
+                                       "not collected in this run", "avg_launch_ms": dom["avg_ms"],
                      "bytes_per_launch": dom["algorithmic_bytes"], "frames_per_launch": round(frames_per_call, 1)},
         "roofline_groups": groups,
         "path": {"bytes_per_frame": path_bytes, "object_bytes_per_frame": round(obj_bytes, 1),
                  "frac_of_hbm_peak_per_gpu": round(fps / world * path_bytes / (HBM_PEAK_GBS * 1e9), 4),
                  "frac_of_hbm_peak_per_gpu_with_objects": round(fps / world * (path_bytes + obj_bytes) / (HBM_PEAK_GBS * 1e9), 4),
-                 "contexts": ns, "driver": args.driver, "results_checked_after_timed_region": checked,
+                 "contexts": ns, "driver": args.driver, "contexts_consistent_after_timed_region": checked,   # the contexts' results against a single-context run of the library
+                                                                      # (consistency of what was timed; parity with the oracle is tests/)
                  # the band kernel's scan order of the contexts after the run (1: block index, 0: tickets) and how often one of them
                  # had to give the index order up (a timed-out scan: the batch is repeated inside the call)
                  "band_scan_order": [s_.tuning_state()["band_order"] for s_ in segs],
                  "band_scan_fallbacks": sum(s_.tuning_state()["band_order_fallbacks"] for s_ in segs),
-                 "ranks_seen": dist.get_world_size() if dist_on else 1,
+                 "ranks_seen": dist.get_world_size() if dist_on else 1, "launch": launch,
                  "halo_overhead": round(halo, 4) if strong else 0.0,
                  "table_gather_messages_per_step": n_gather if dist_on else None,
                  "table_gather_ms_per_step_rank0": round(stats["gather_s"] / max(args.steps, 1) * 1e3, 3) if dist_on else None},

@@ -84,15 +84,27 @@ TABLE_FIELDS = [w[0] for w in _WIRE]
 _MAGIC = 0x50534547544142                          # "PSEGTAB"
 
 
+def packed_bytes(tab):
+    """bytes pack_table needs for this table"""
+    F, R, S = int(tab.n_frames), len(tab.frame), len(tab.saved_row)
+    return 48 + sum(int(np.prod(shape(F, R, S))) * np.dtype(dt).itemsize for _, dt, shape in _WIRE)
+
+
 def pack_table(tab, frame_base=0, out=None):
     """Object table -> one uint8 blob: a 6-word int64 header, then the arrays back to back in _WIRE order (plain
     memcpy -- this runs once per batch next to the kernels).  Frame indices are made global.  ``out``: a uint8 buffer
-    to reuse (a view of it is returned when it is large enough; fresh pages cost more than the copy)."""
+    to write into (fresh pages cost more than the copy); the returned array is a view of it, and a buffer that is too
+    small raises ValueError -- a caller that keeps its own fill count must never be handed a fresh array silently."""
     F, R, S = int(tab.n_frames), len(tab.frame), len(tab.saved_row)
     head = np.asarray([_MAGIC, F, frame_base, tab.crop_bytes, R, S], np.int64)
     sizes = [int(np.prod(shape(F, R, S))) * np.dtype(dt).itemsize for _, dt, shape in _WIRE]
     total = 48 + sum(sizes)
-    out = out[:total] if out is not None and out.size >= total else np.empty(total, np.uint8)
+    if out is None:
+        out = np.empty(total, np.uint8)
+    elif out.size < total:
+        raise ValueError(f"pack_table: the buffer holds {out.size} bytes, the table needs {total}")
+    else:
+        out = out[:total]
     out[:48] = head.view(np.uint8)
     o = 48
     for (name, dt, shape), nb in zip(_WIRE, sizes):

@@ -202,3 +202,40 @@ def test_plan_ranges_covers_every_frame_once_with_local_windows(n_files, world):
                     assert local + (s - bs) == start
     assert (owner >= 0).all()
     assert (np.diff(owner) >= 0).all(), "ranks own contiguous, ordered ranges"
+
+
+def _bench(*argv, env=None):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *argv], env=e, capture_output=True, text=True, timeout=300)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+@pytest.mark.parametrize("n", [2, 3])
+def test_bench_gpus_n_starts_n_ranks_itself(n):
+    """`python3 bench.py --gpus N` (no torchrun, no WORLD_SIZE) must run N ranks: the launcher starts them, rank 0 prints the
+    one line, the parent checks n_gpus and ranks_seen against --gpus.  --plan-only: process group + plan_ranges + gathers of
+    empty tables, no kernels (this container has no GPU)."""
+    r, line = _bench("--gpus", str(n), "--backend", "gloo", "--plan-only", "--frames", "2000")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len([ln for ln in r.stdout.splitlines() if ln.strip()]) == 1, "exactly one line on stdout"
+    assert line["n_gpus"] == n and line["ranks_seen"] == n and line["launch"] == "self-spawned"
+    assert line["frames_merged"] == 2000 and sum(line["frames_per_rank"]) == 2000 and len(line["frames_per_rank"]) == n
+    assert max(line["halo_frames_per_rank"]) <= 11 * max(line["parts_per_rank"])
+
+
+def test_bench_refuses_a_world_that_is_not_gpus():
+    """--gpus 4 inside a 1-rank world (the way round 2's bench silently ran one rank) is an error, not a 1-rank number"""
+    r, line = _bench("--gpus", "4", "--backend", "gloo", "--plan-only", env={"WORLD_SIZE": "1", "RANK": "0"})
+    assert r.returncode != 0 and line is None
+    assert "WORLD_SIZE" in r.stderr
+
+
+def test_bench_launcher_fails_when_a_rank_fails():
+    r, line = _bench("--gpus", "2", "--backend", "gloo", "--plan-only", "--frames", "-5")
+    assert r.returncode != 0 and line is None
