@@ -193,7 +193,12 @@ def main():
     if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
         raise SystemExit(f"bench: --gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE')}: the ranks that run must be --gpus")
     if args.plan_only:
+        sys.stdout.flush()
+        real_stdout = os.dup(1)                              # (gloo prints a banner to stdout: ONE line is the contract)
+        os.dup2(2, 1)
         line = plan_only(args, int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), launch)
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
         if line is not None:
             print(json.dumps(line), flush=True)
         return

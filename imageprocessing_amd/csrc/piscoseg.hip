@@ -67,6 +67,8 @@ struct pseg_ctx {
     size_t head_copy_off = 0, head_copy_bytes = 0;
     int head_n = -1;
     PinBuf pin_head, pin_tail, pin_nfg;
+    PinBuf pin_rp;                // 256 B for the sums pseg_regionprops_noalloc copies back (allocated in pseg_create: that
+                                  // entry point allocates nothing, not even through the runtime's staging of a pageable copy)
     DevBuf outpack;               // sums | crop_off | rows (10 columns) | saved_row, packed for ONE copy to pin_tail
     bool head_on_host = false;    // pin_head holds this call's head (pseg_process reuses it for the raw statistics)
     // sparse workspaces
@@ -229,7 +231,9 @@ extern "C" int pseg_create(int device, int H, int W, int max_frames, pseg_ctx **
     ctx->own_stream = true;
     ctx->cur = ctx->stream;
     if (hipEventCreateWithFlags(&ctx->ev_turn, hipEventDisableTiming) != hipSuccess) ctx->ev_turn = nullptr;
-    if (rp_static_lookup(device) != hipSuccess) { hipStreamDestroy(ctx->stream); delete ctx; return PSEG_ERR_HIP; }
+    // (a failed lookup only means "no no-alloc entry point on this device": pseg_regionprops_noalloc says so by itself)
+    (void)rp_static_lookup(device);
+    if (hipHostMalloc(&ctx->pin_rp.p, 256, hipHostMallocDefault) == hipSuccess) ctx->pin_rp.bytes = 256; else ctx->pin_rp.p = nullptr;
     if (const char *e = getenv("PSEG_BG_CHUNKS")) ctx->bg_chunks = atoi(e) > 0 ? atoi(e) : 1;
     if (const char *e = getenv("PSEG_BG_GENERIC")) ctx->force_generic = atoi(e) != 0;
     {
@@ -283,7 +287,7 @@ extern "C" int pseg_destroy(pseg_ctx *ctx)
                       &ctx->crops_raw, &ctx->crops_masked, &ctx->crops_mask, &ctx->bounds, &ctx->band_off, &ctx->band_obj, &ctx->scan_part, &ctx->trash, &ctx->rp_small, &ctx->rp_scratch, &ctx->resize_tab,
                       &ctx->synth_objs, &ctx->synth_off};
     for (DevBuf *b : bufs) if (b->p) hipFree(b->p);
-    for (PinBuf *b : {&ctx->pin_head, &ctx->pin_tail, &ctx->pin_nfg}) if (b->p) hipHostFree(b->p);
+    for (PinBuf *b : {&ctx->pin_head, &ctx->pin_tail, &ctx->pin_nfg, &ctx->pin_rp}) if (b->p) hipHostFree(b->p);
     for (auto &e : ctx->ev) if (e) hipEventDestroy(e);
     if (ctx->ev_turn) hipEventDestroy(ctx->ev_turn);
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
@@ -1122,7 +1126,8 @@ extern "C" int pseg_submit(pseg_ctx *ctx, const uint8_t *frames, int n_avail, in
     }
     AsyncWorker *w = ctx->worker;
     std::lock_guard<std::mutex> lk(w->mu);
-    if (w->have_job || w->done) return fail(ctx, PSEG_ERR_ARG, "pseg_submit: the previous submission has not been waited for");
+    // (no text for pseg_last_error here: the worker may be writing ctx->err inside the call that is still in flight)
+    if (w->have_job || w->done) return PSEG_ERR_ARG;
     w->a = {frames, n_avail, n_emit, batch_len, n_bg_imgs, mask, threshold, min_area_to_segment, min_area_to_save, cleaned, mean_std, valid, labels};
     w->have_job = true;
     w->cv.notify_all();
@@ -1381,7 +1386,7 @@ extern "C" int pseg_regionprops_noalloc(pseg_ctx *ctx, const uint8_t *mask, cons
                     " pixels); use pseg_regionprops");
     const int rpb = crop_rows_per_band(w), nbands = (h + rpb - 1) / rpb;
     if (nbands > RP_NA_MAX_BANDS) return fail(ctx, PSEG_ERR_CAPACITY, "pseg_regionprops_noalloc: too many row bands");
-    if (ctx->device < 0 || ctx->device >= PSEG_MAX_DEVICES || !g_rp_static_ptr[ctx->device])
+    if (ctx->device < 0 || ctx->device >= PSEG_MAX_DEVICES || !g_rp_static_ptr[ctx->device] || !ctx->pin_rp.p)
         return fail(ctx, PSEG_ERR_HIP, "pseg_regionprops_noalloc: no static scratch on this device");
     HIPCHK(hipSetDevice(ctx->device));
     std::lock_guard<std::mutex> lk(g_rp_static_mu[ctx->device]);
@@ -1401,9 +1406,12 @@ extern "C" int pseg_regionprops_noalloc(pseg_ctx *ctx, const uint8_t *mask, cons
     hipLaunchKernelGGL(k_convex, dim3(1), dim3(128), lds, st, 1, (const int32_t *)(d + RP_NA_O_GEO), (const long long *)(d + RP_NA_O_LL + 32),
                        (const int32_t *)(d + RP_NA_O_EXT), d_sums, 0, h);
     HIPCHK(hipGetLastError());
+    // the sums come back into the context's page-locked buffer (a single DMA write; a pageable destination would go through a
+    // staging buffer of the runtime's).  The call ends with a stream synchronisation: it is not for streams under capture.
     int64_t q[PSEG_NSUMS];
-    HIPCHK(hipMemcpyAsync(q, d_sums, sizeof(q), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(ctx->pin_rp.p, d_sums, sizeof(q), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    memcpy(q, ctx->pin_rp.p, sizeof(q));
     if (q[0] == 0) {
         for (int k = 0; k < PSEG_NPROPS; k++) props[k] = NAN;
         return fail(ctx, PSEG_ERR_ARG, "mask has no set pixel");

@@ -135,11 +135,35 @@ def _write_frame(tab, f, fn, mean_raw, settings, saved_of_row):
     save_crop_data(os.path.join(settings.data_path, fn[:-4] + ".csv"), rows)                               # :293
 
 
+def check_settings(settings):
+    """Settings the reference acts on and this path does not are refused, never ignored.  ``resize`` (detection.py:209-218:
+    areas x 4, boxes x 2 for frames that were halved upstream, then crops cut from the unscaled frame at the doubled
+    coordinates) is off in every settings literal of the reference (segmenter.py:185-201) and has no device form here."""
+    if settings.resize:
+        raise NotImplementedError("DetectionSettings.resize=True (detection.py:209-218) is not supported by the GPU path; "
+                                  "the reference's own callers pass False (segmenter.py:196)")
+
+
+def _write_overview_images(cleaned, good, tab, settings, device):
+    """detection.py:275-277 (save_bb_image): the cleaned frame as a 3-channel image, cv.resize'd to 1280 x 1280, written to
+    img_path under the frame's own file name (the contour drawing above it is commented out in the reference, :230-231).
+    The resize runs on the device (pseg_resize_frames = OpenCV's INTER_LINEAR / exact 2 x 2 averaging restated)."""
+    from PIL import Image
+    n = cleaned.shape[0]
+    half = _segmenter(1280, 1280, n, device, role="overview")
+    with half.lock:
+        small = half.resize_frames(cleaned.contiguous()).cpu().numpy()
+    for f in range(n):
+        if tab.frame_valid[f]:                               # (corrupt frames take the else branch: no image)
+            Image.fromarray(np.repeat(small[f][:, :, None], 3, axis=2)).save(os.path.join(settings.img_path, good[f][3]))
+
+
 def detect_batch(items, settings, mask, n_writers=8, device=0):
     """All frames of a batch in one library call + host-side file writing.  ``items`` are the tuples of the
     background stage; ``mask`` is the uint8 disk mask (numpy array or device tensor)."""
     import torch
     dev = f"cuda:{device}"
+    check_settings(settings)
     good = [it for it in items if not isinstance(it[1], list)]
     for it in items:
         if isinstance(it[1], list):                                      # corrupt frame (detection.py:294-297)
@@ -171,6 +195,13 @@ def detect_batch(items, settings, mask, n_writers=8, device=0):
                          min_area_to_segment=settings.min_area_to_segment, min_area_to_save=settings.min_area_to_save,
                          fetch_crops="pinned" if settings.save_crops else False)
         saved_of_row = {int(r): s for s, r in enumerate(tab.saved_row)}
+        if not settings.save_crops and len(tab.saved_row):
+            # detection.py:237-258: with save_crops False the crops and c_mask are never made, and the first object above
+            # min_area_to_save reaches calculate_regionprops(c_mask, ...) with c_mask undefined -- the reference dies there
+            raise NameError("name 'c_mask' is not defined (detection.py:257): save_crops=False with an object above "
+                            "min_area_to_save; no file of this batch was written")
+        if settings.save_bb_image:
+            _write_overview_images(cleaned, good, tab, settings, device)
         with ThreadPoolExecutor(max_workers=max(1, n_writers)) as ex:
             list(ex.map(lambda f: _write_frame(tab, f, good[f][3], good[f][2], settings, saved_of_row), range(len(good))))
         if tab.crops:

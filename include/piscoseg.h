@@ -128,7 +128,7 @@ int pseg_process_batches(pseg_ctx *ctx, const uint8_t *frames, int n, int batch_
  * context owns a worker thread inside the library: pseg_submit hands it the arguments of pseg_process_part (batch_len == 0)
  * or pseg_process_batches (batch_len > 0, n_emit == n_avail) and returns at once; pseg_wait blocks until that call has
  * finished, returns its status and fills *out.  All pointers must stay valid until pseg_wait returns; one submission in flight
- * per context (a second pseg_submit before pseg_wait is PSEG_ERR_ARG).  With two or three contexts on one GPU --
+ * per context (a second pseg_submit before pseg_wait is PSEG_ERR_ARG, and leaves pseg_last_error alone: the call in flight owns it).  With two or three contexts on one GPU --
  * submit(A), submit(B), wait(A), submit(A), wait(B), ... -- the host round trips and the table epilogue of one batch hide
  * under the kernels of the next, without any thread on the caller's side.  Results are identical to the synchronous calls. */
 int pseg_submit(pseg_ctx *ctx, const uint8_t *frames, int n_avail, int n_emit, int batch_len, int n_bg_imgs,
@@ -150,13 +150,15 @@ int pseg_regionprops(pseg_ctx *ctx, const uint8_t *mask, const uint8_t *img, int
                      double *props, int64_t *sums_out);
 
 /* pseg_regionprops for callers that cannot allocate.  NO COUNTERPART IN THE REFERENCE: it exists for callers that must not
- * reach hipMalloc / hipFree -- code under HIP graph capture, tight serving loops, harnesses that forbid allocation.  Same
- * arguments, same kernels and bit-identical results as pseg_regionprops; the scratch (tables, sums, row extremes and the
- * three crop planes the band kernel writes) is a file-scope device array of about 0.8 MB that every GPU the library runs on
- * holds until the process ends, so the window is limited: h <= PSEG_NOALLOC_MAX_ROWS, w <= 8192 and
- * w * h <= PSEG_NOALLOC_MAX_PIXELS (PSEG_ERR_CAPACITY beyond that).  The call allocates nothing, on the device or through
- * the runtime.  All calls on one GPU share the array: calls made through this library in one process are serialised by a
- * per-device lock; anything else that overlaps them on the same array would race. */
+ * reach hipMalloc / hipFree -- tight serving loops, harnesses that forbid allocation after start-up.  Same arguments, same
+ * kernels and bit-identical results as pseg_regionprops; the scratch (tables, sums, row extremes and the three crop planes
+ * the band kernel writes) is a file-scope device array of about 0.8 MB that every GPU the library runs on holds until the
+ * process ends, so the window is limited: h <= PSEG_NOALLOC_MAX_ROWS, w <= 8192 and w * h <= PSEG_NOALLOC_MAX_PIXELS
+ * (PSEG_ERR_CAPACITY beyond that).  The call allocates nothing: no hipMalloc / hipFree / hipHostMalloc, and the 192 bytes of
+ * sums come back into a page-locked buffer that pseg_create made (no pageable staging inside the runtime).  It does END WITH A
+ * STREAM SYNCHRONISATION (props is host memory), so it cannot run on a stream that is being captured into a HIP graph.
+ * All calls on one GPU share the array: calls made through this library in one process are serialised by a per-device
+ * lock; anything else that overlaps them on the same array would race. */
 #define PSEG_NOALLOC_MAX_PIXELS 262144
 #define PSEG_NOALLOC_MAX_ROWS 1024
 int pseg_regionprops_noalloc(pseg_ctx *ctx, const uint8_t *mask, const uint8_t *img, int h, int w, int stride,

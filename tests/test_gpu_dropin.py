@@ -76,6 +76,45 @@ def test_stage_functions_write_reference_files(tmp_path):
             assert np.array_equal(np.asarray(Image.open(os.path.join(dirs["Masks"], fn))), cmask)
 
 
+def test_save_bb_image_and_save_crops_false(tmp_path):
+    """detection.py:275-277: save_bb_image writes the cleaned frame, cv.resize'd to 1280 x 1280, as a 3-channel image under the
+    frame's name; detection.py:237-258: save_crops=False dies with NameError at the first object above min_area_to_save
+    (before any file of the batch is written here) and runs through when nothing is saved."""
+    from PIL import Image
+    from imageprocessing_amd import detection, synth
+    from oracle import cv_resize_ref
+    H = W = 256
+    n = 12
+    objs, off = synth.make_objects(n, H, W, 23, per_frame=8, dmin=40, dmax=700)
+    stack = synth.render(n, H, W, 23, objs, off)
+    stack[3] = 77                                            # corrupt frame: no overview image
+    names = [f"SO298_{i:04d}_img.png" for i in range(n)]
+    items = [(it[0], it[1], it[2], nm) for it, nm in zip(helpers.oracle_bgcorrect(stack), names)]
+    dirs = {k: str(tmp_path / k) for k in ("Data", "Crops", "Deconv_crops", "Masks", "Images")}
+    for d in dirs.values():
+        os.makedirs(d)
+    mask = helpers.make_disk(H, W, 120)
+    st = detection.DetectionSettings(dirs["Data"], dirs["Crops"], dirs["Deconv_crops"], dirs["Masks"], dirs["Images"],
+                                     400, 10, 1, True, True, True, False, True, True, 120)
+    detection.detect_batch(items, st, mask, n_writers=2)
+    assert sorted(os.listdir(dirs["Images"])) == [nm for i, nm in enumerate(names) if i != 3]
+    for i in (0, 7):
+        got = np.asarray(Image.open(os.path.join(dirs["Images"], names[i])))
+        want = cv_resize_ref.resize_linear_u8(items[i][1], 1280, 1280)
+        assert got.shape == (1280, 1280, 3) and all(np.array_equal(got[:, :, ch], want) for ch in range(3))
+    # save_crops=False
+    for d in ("Data", "Crops"):
+        for fn in os.listdir(dirs[d]):
+            os.remove(os.path.join(dirs[d], fn))
+    st.save_bb_image, st.save_crops = False, False
+    with pytest.raises(NameError, match="c_mask"):
+        detection.detect_batch(items, st, mask, n_writers=2)
+    assert [fn for fn in os.listdir(dirs["Data"]) if fn != names[3][:-4] + ".csv"] == []
+    st.min_area_to_save = 1e9                                 # nothing saved: every row is an unsaved row, no crops
+    detection.detect_batch(items, st, mask, n_writers=2)
+    assert len(os.listdir(dirs["Data"])) == n and os.listdir(dirs["Crops"]) == []
+
+
 def test_correct_img_single_index():
     from imageprocessing_amd import bg_correction, reader
     rng = np.random.default_rng(3)
@@ -360,7 +399,7 @@ def test_crop_dataframe_from_device_table_equals_csv_round_trip(tmp_path):
     for d in dirs.values():
         os.makedirs(d)
     settings = detection.DetectionSettings(dirs["Data"], dirs["Crops"], dirs["Deconv_crops"], dirs["Masks"], dirs["Images"],
-                                           400, 10, 1, False, False, True, False, True, True, 120)
+                                           400, 10, 1, False, True, True, False, True, True, 120)
     tab = detection.detect_batch(items, settings, helpers.make_disk(H, W, 120), n_writers=4)
     good = [it for it in items if not isinstance(it[1], list)]
     got = tables.crop_dataframe(tab, [it[3] for it in good], [it[2] for it in good], dirs["Data"])

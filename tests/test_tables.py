@@ -71,3 +71,16 @@ def test_crop_dataframe_equals_gen_crop_df_of_the_csv_files(tmp_path, min_save, 
     pd.testing.assert_frame_equal(got, want, check_exact=False, rtol=1e-12, atol=0)
     assert got["img_id"].is_monotonic_increasing and got["img_id"].iloc[0] == 1
     assert os.path.dirname(got["full_path"].iloc[0]) == str(data)
+
+
+def test_settings_the_gpu_path_does_not_implement_are_refused():
+    """a drop-in refuses what it does not do (detection.py:209-218 `resize`), it does not ignore it; no GPU needed"""
+    import pytest
+    from imageprocessing_amd import detection
+    s = detection.DetectionSettings("d", "c", "dc", "m", "i", 400, 10, 1, False, True, True, True, True, True, 1200)
+    with pytest.raises(NotImplementedError, match="resize"):
+        detection.check_settings(s)
+    with pytest.raises(NotImplementedError, match="resize"):
+        detection.detect_batch([], s, None)
+    s.resize = False
+    detection.check_settings(s)

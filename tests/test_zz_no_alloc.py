@@ -77,3 +77,38 @@ def test_noalloc_limits_and_second_context():
     finally:
         a.close()
         b.close()
+
+
+def test_noalloc_moves_no_device_memory_over_100_calls():
+    """free device memory (hipMemGetInfo through torch) is the same before and after 100 calls with changing window sizes;
+    the growing-buffer entry point pseg_regionprops, by contrast, may allocate when a window outgrows its buffers"""
+    import torch
+    from imageprocessing_amd.engine import Segmenter
+    seg = Segmenter(256, 256, max_frames=2, device=0)
+    rng = np.random.default_rng(7)
+    try:
+        shapes = [(int(rng.integers(1, 1025)), 0) for _ in range(100)]
+        shapes = [(h, int(rng.integers(1, min(8192, 262144 // h) + 1))) for h, _ in shapes]
+        hmax = max(h for h, _ in shapes)
+        wmax = max(w for _, w in shapes)
+        mbuf = torch.zeros((1024, 8192), dtype=torch.uint8, device="cuda")
+        gbuf = torch.randint(0, 256, (1024, 8192), dtype=torch.uint8, device="cuda")
+        mbuf[:hmax, :wmax] = (torch.rand((hmax, wmax), device="cuda") < 0.6).to(torch.uint8) * 255
+        mbuf[:, 0] = 255
+        mbuf[0, :] = 255
+        props = np.zeros(32)
+        sums = np.zeros(24, np.int64)
+        # warm-up: kernels loaded, the stream's first use
+        assert seg.L.pseg_regionprops_noalloc(seg.h, mbuf.data_ptr(), gbuf.data_ptr(), 16, 16, 8192, props.ctypes.data, sums.ctypes.data) == 0
+        torch.cuda.synchronize()
+        free0, _ = torch.cuda.mem_get_info()
+        for h, w in shapes:
+            rc = seg.L.pseg_regionprops_noalloc(seg.h, mbuf.data_ptr(), gbuf.data_ptr(), h, w, 8192, props.ctypes.data, sums.ctypes.data)
+            assert rc == 0, (h, w, seg.L.pseg_last_error(seg.h))
+        torch.cuda.synchronize()
+        free1, _ = torch.cuda.mem_get_info()
+        assert free1 == free0, (free0, free1)
+        h, w = shapes[-1]
+        assert sums[0] == int((mbuf[:h, :w] == 255).sum().item())
+    finally:
+        seg.close()
