@@ -41,7 +41,7 @@ BATCH = 200
 GATHER_EVERY = 4                           # library calls per table gather (N > 1)
 HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: 8.0 TB/s spec peak
 PATH_BYTES_PER_FRAME = 6 * P               # raw read + cleaned write + int32 label write
-GROUP_NAMES = {0: "bg_correct", 2: "sparse_labelling", 3: "label_map", 4: "crops_props"}
+GROUP_NAMES = {0: "bg_correct", 2: "sparse_labelling", 3: "label_map", 4: "crops_props"}   # (+ 1: "threshold" with --deconv-standin)
 
 
 def group_bytes_per_frame(name, rows_pf, crop_bytes_pf, labels_on):
@@ -50,6 +50,8 @@ def group_bytes_per_frame(name, rows_pf, crop_bytes_pf, labels_on):
         return 2 * P + P // 8              # raw read once, cleaned written once, the 1-bit threshold plane written
     if name == "label_map":
         return 4 * P if labels_on else 0   # int32 label map written once
+    if name == "threshold":
+        return P + P // 8                  # the (deconvolved) cleaned frame read once, the 1-bit threshold plane written
     if name == "sparse_labelling":
         return P // 8                      # the threshold plane read once
     return 4 * crop_bytes_pf + 44 * 8 * rows_pf      # crops: one read + three planes written; the rows of the table
@@ -180,6 +182,9 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="run the N > 1 code path (frame ranges, process group, table gathers on "
                     "their thread) with a world of one rank: all a one-GPU box allows through RCCL")
     ap.add_argument("--host-batches", type=int, default=6, help="batches of the host-input measurement (0 = skip)")
+    ap.add_argument("--deconv-standin", action="store_true", help="the reference's default two-call path (run_pipeline.py:25, "
+                    "segmenter.py:243-254): pseg_bgcorrect -> an elementwise stand-in for the deconvolution network on the device -> "
+                    "pseg_detect(cleaned = its output, raw = the background-corrected frames); adds the `threshold` group")
     ap.add_argument("--plan-only", action="store_true", help="process group + frame-range plan + gathers of empty tables over gloo; "
                     "no kernels, no GPU (the launcher's CPU test)")
     ap.add_argument("--n-bg-imgs", type=int, default=6, help="half the background window (bg_correction.py:65; reference: 6)")
@@ -233,6 +238,11 @@ def main():
     cdev = dev if args.backend == "nccl" else "cpu"        # where the collectives' tensors live
 
     strong = dist_on and args.scaling == "strong"
+    if args.deconv_standin:
+        if dist_on:
+            raise SystemExit("bench: --deconv-standin is a single-GPU variant")
+        args.driver = "threads"                              # two library calls per batch: one host thread per context
+        GROUP_NAMES[1] = "threshold"
     total_frames = args.frames or (10000 if strong else 2000)
     cfg = synth.CONFIGS[args.workload]
     ns = max(1, args.streams)
@@ -260,6 +270,7 @@ def main():
         seg.synth_frames(m, seed, objs, off, frame0=g0 + a, out=stack[a:a + m])
     cleaned = [torch.empty((max_call, H, W), dtype=torch.uint8, device=dev) for _ in range(ns)]
     labels = [torch.empty((max_call, H, W), dtype=torch.int32, device=dev) if labels_on else None for _ in range(ns)]
+    deconv = [torch.empty((max_call, H, W), dtype=torch.uint8, device=dev) for _ in range(ns)] if args.deconv_standin else None
     emitted = sum(c[1] for c in calls)
     loaded = sum(c[2] for c in calls)
 
@@ -394,6 +405,16 @@ def main():
                 for i in range(k, total, ns):
                     c = i % nc
                     a, ne, na, _ = calls[c]
+                    if args.deconv_standin:
+                        cb, _, v = segs[k].bgcorrect(stack[a:a + na], n_bg_imgs=args.n_bg_imgs, cleaned=cleaned[k][:na])
+                        ms_bg = segs[k].last_ms(0)
+                        torch.bitwise_or(cb, 0, out=deconv[k][:na])                # elementwise stand-in for the network (its output
+                        tab = segs[k].detect(deconv[k][:na], raw=cb, mask=mask, valid=v,   # equals its input: results stay checkable)
+                                             labels=None if labels[k] is None else labels[k][:na])
+                        ms = {g: segs[k].last_ms(g) for g in GROUP_NAMES}
+                        ms[0] = ms_bg
+                        out_q.put((i, k, tab, ms))
+                        continue
                     tab = segs[k].process(stack[a:a + na], **kwargs(c, k))[3]
                     out_q.put((i, k, tab, {g: segs[k].last_ms(g) for g in GROUP_NAMES}))
             ths = [threading.Thread(target=work, args=(k,)) for k in range(ns)]
@@ -453,6 +474,18 @@ def main():
             same = same and (not labels_on or torch.equal(labels[k][:ne], want_l))
             same = same and all(np.array_equal(getattr(t_, f), ref[f], equal_nan=True) for f in ref)
             checked = checked and bool(same)
+        if args.deconv_standin:
+            # the two-call path alone on one context: its groups with the GPU to themselves, its results against the fused call
+            cb, ms_b, v_b = segs[0].bgcorrect(stack[a:a + na], n_bg_imgs=args.n_bg_imgs, cleaned=cleaned[0][:na])
+            iso_ms[0] = segs[0].last_ms(0)
+            torch.bitwise_or(cb, 0, out=deconv[0][:na])
+            t_ = segs[0].detect(deconv[0][:na], raw=cb, mask=mask, valid=v_b, labels=None if labels[0] is None else labels[0][:na])
+            for k in (1, 2, 3, 4):
+                iso_ms[k] = segs[0].last_ms(k)
+            same = torch.equal(cb[okv], want_c[okv]) and np.array_equal(ms_b, ms0) and np.array_equal(v_b, v0)
+            same = same and (not labels_on or torch.equal(labels[0][:ne], want_l))
+            same = same and all(np.array_equal(getattr(t_, f), ref[f], equal_nan=True) for f in ref)
+            checked = checked and bool(same)
         del want_c, want_l
         if not checked:
             raise SystemExit("bench: the contexts' results differ from the single-context run")
@@ -491,6 +524,8 @@ def main():
     else:
         idx = 1 if args.workload == "pisco" else 3
         wl = (f"configs[{idx}]: {total_frames}-frame {args.workload} stack{' per GPU' if world > 1 else ''}, batches of {BATCH}")
+        if args.deconv_standin:
+            wl += ", two-call path (pseg_bgcorrect -> elementwise stand-in for the deconvolution network -> pseg_detect)"
     out = {
         "metric": "frames/sec (2560x2560 uint8), hot path bg_correction+detection",
         "value": round(fps, 2), "unit": "frames/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,

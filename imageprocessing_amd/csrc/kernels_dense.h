@@ -100,7 +100,8 @@ __global__ __launch_bounds__(256) void k_bg_generic(const uint8_t *__restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
-// streaming background kernel (window of 12 frames = the reference's 2*n_bg_imgs with n_bg_imgs = 6)
+// streaming background kernel (window NW = 2*n_bg_imgs frames; the notes below are written for the reference's NW = 12,
+// n_bg_imgs = 6 -- the other windows differ in the last combination of the sparse table, see BgWin)
 //
 // A thread owns one 8-pixel strip and walks the frames of its time chunk [a, b) in order, so every
 // raw byte is read from HBM once (plus an 11-frame halo per chunk) instead of 12 times.
@@ -251,42 +252,66 @@ __device__ __forceinline__ void bg_flush(const BgEmit &E, const BgSums &A, int s
     }
 }
 
-// Per-thread state.  The 12-frame history of raw pixels lives in an LDS ring (dynamic slot index,
-// private to the thread: no barriers); the sparse table and 4 prefetched frames live in registers
-// with compile-time phases (loop unrolled by 4).
+// Per-thread state.  The history of raw pixels (NW frames) lives in an LDS ring (dynamic slot index, private to the thread:
+// no barriers); the sparse table and 4 prefetched frames live in registers with compile-time phases (loop unrolled by 4,
+// by 8 for windows whose T8 history is deeper than 4 steps).
+// Window NW = 2 * n_bg_imgs frames (bg_correction.py:65) -> M = NW - 1 pair minima per background:
+//   M in 8 .. 15:  TM[j] = max(T8[j], T8[j - (M - 8)])      (NW = 10: T8[j-1], 12: T8[j-3], 14: T8[j-5], 16: T8[j-7])
+//   M in 4 .. 7:   TM[j] = max(T4[j], T4[j - (M - 4)])      (NW = 6: T4[j-1], 8: T4[j-3])
+//   M = 3:         TM[j] = max(T2[j], T2[j - 1])            (NW = 4)
+template <int NW> struct BgWin {
+    static constexpr int M = NW - 1;
+    static constexpr int D8 = M >= 8 ? M - 8 : 0;           // steps back into the T8 history
+    static constexpr int T8N = D8 > 4 ? 8 : 4;              // its ring
+    static constexpr int U = D8 > 4 ? 8 : 4;                // loop unroll (phases)
+    static constexpr int BLOCKS = D8 > 4 ? 3 : 4;           // blocks per CU: the ring of eight T8 entries takes 16 registers more
+                                                            // than 4 blocks per CU leave a thread (128; 20 - 26 spilled)
+    static_assert(NW >= 4 && NW <= 16 && NW % 2 == 0, "window of 4 .. 16 frames");
+};
+template <int NW>
 struct BgRegs {
-    uint2 pf[4];           // frames k .. k+3 (pf[PH] is the frame of the current step)
+    uint2 pf[4];           // frames k .. k+3 (pf[PH & 3] is the frame of the current step)
     Px8 prev;              // frame k-1, split
-    Px8 mp, t2[2], t4[4], t8[4], last;
+    Px8 mp, t2[2], t4[4], t8[BgWin<NW>::T8N], last;
     BgSums acc;            // per-lane sums of the frames emitted by the last (up to) four steps
 };
 #define BG_SLOTS 16
-template <int PH, bool PAD>
-__device__ __forceinline__ void bg_step(BgRegs &R, uint2 *ring, const BgEmit &E, const uint8_t *__restrict__ src, int k, int a,
+template <int PH, int NW, bool PAD>
+__device__ __forceinline__ void bg_step(BgRegs<NW> &R, uint2 *ring, const BgEmit &E, const uint8_t *__restrict__ src, int k, int a,
                                         int kend, int n)
 {
-    const uint2 cur = R.pf[PH];
+    constexpr int M = BgWin<NW>::M, T8M = BgWin<NW>::T8N - 1;
+    const uint2 cur = R.pf[PH & 3];
     int kn = k + 4 <= kend ? k + 4 : kend;                  // clamped prefetch: always a valid frame
-    R.pf[PH] = ld_stream_at(src + (size_t)kn * E.P, E.off8);   // src is wave-uniform
+    R.pf[PH & 3] = ld_stream_at(src + (size_t)kn * E.P, E.off8);   // src is wave-uniform
     ring[(k & (BG_SLOTS - 1)) * 256] = cur;
-    const uint2 old = ring[((k - 11) & (BG_SLOTS - 1)) * 256];   // frame k-11 (zeros during warm-up)
+    const uint2 old = ring[((k - (NW - 1)) & (BG_SLOTS - 1)) * 256];   // frame k-(NW-1) (zeros during warm-up)
     const Px8 cs = px_split(cur);
     Px8 m = px_min(R.prev, cs);                             // pair minimum m[k-1]
     if (k == a) m = Px8{0, 0, 0, 0};                         // no pair yet at the first frame of the chunk
     R.prev = cs;
     Px8 t2 = px_max(m, R.mp); R.mp = m;
-    Px8 t4 = px_max(t2, R.t2[(PH + 1) & 1]); R.t2[(PH + 1) & 1] = t2;
-    Px8 t8 = px_max(t4, R.t4[(PH + 3) & 3]); R.t4[(PH + 3) & 3] = t4;
-    Px8 t11 = px_max(t8, R.t8[PH & 3]); R.t8[(PH + 3) & 3] = t8;
-    R.last = t11;
-    bg_emit<PAD>(E, old, px_split(old), t11, k - 11, k - 11 >= a && k < n - 1, R.acc.p[PH], R.acc.s1[PH], R.acc.s3[PH]);
+    Px8 tm;
+    if constexpr (M < 4) {
+        tm = px_max(t2, R.t2[(PH + 1) & 1]); R.t2[PH & 1] = t2;
+    } else {
+        Px8 t4 = px_max(t2, R.t2[PH & 1]); R.t2[PH & 1] = t2;            // (slot written two steps ago: read, then replaced)
+        if constexpr (M < 8) {
+            tm = M == 4 ? t4 : px_max(t4, R.t4[(PH + 8 - (M - 4)) & 3]); R.t4[PH & 3] = t4;
+        } else {
+            Px8 t8 = px_max(t4, R.t4[PH & 3]); R.t4[PH & 3] = t4;        // (written four steps ago)
+            tm = M == 8 ? t8 : px_max(t8, R.t8[(PH + 16 - (M - 8)) & T8M]); R.t8[PH & T8M] = t8;
+        }
+    }
+    R.last = tm;
+    bg_emit<PAD>(E, old, px_split(old), tm, k - (NW - 1), k - (NW - 1) >= a && k < n - 1, R.acc.p[PH & 3], R.acc.s1[PH & 3], R.acc.s3[PH & 3]);
 }
 
 // grid = (ceil(P/2048), chunks); chunk c emits frames [bounds[c], bounds[c+1]) of the reference batch that ends at frame
 // bounds[chunks + 1 + c] (several batches in one launch: every batch is at least one chunk).  PAD: the last block has lanes
-// beyond the frame (P % 2048 != 0).
-template <bool PAD>
-__global__ __launch_bounds__(256, 4) void k_bg_stream(const uint8_t *__restrict__ frames, size_t P, uint8_t *__restrict__ cleaned,
+// beyond the frame (P % 2048 != 0).  NW: the window (2 * n_bg_imgs frames).
+template <int NW, bool PAD>
+__global__ __launch_bounds__(256, BgWin<NW>::BLOCKS) void k_bg_stream(const uint8_t *__restrict__ frames, size_t P, uint8_t *__restrict__ cleaned,
                                                       const uint8_t *__restrict__ mask, int thr, uint8_t *__restrict__ bits8,
                                                       uint4 *__restrict__ partials, const int *__restrict__ bounds,
                                                       uint8_t *__restrict__ trash, uint32_t *__restrict__ maskpart,
@@ -307,7 +332,7 @@ __global__ __launch_bounds__(256, 4) void k_bg_stream(const uint8_t *__restrict_
     if (!act) strip = 0;
     const int a = bounds[bi], b = bounds[bi + 1];
     const int n = bounds[gridDim.y + 1 + blockIdx.y];        // end of the reference batch this chunk belongs to
-    const int kend = (b == n) ? n - 1 : b + 10;
+    const int kend = (b == n) ? n - 1 : b + NW - 2;
     BgEmit E;
     E.cleaned = cleaned; E.bits8 = bits8; E.partials = partials; E.P = P;
     E.strip32 = (uint32_t)strip; E.off8 = (uint32_t)strip * 8u;             // P <= 2^29: lane offsets fit 32 bits
@@ -330,57 +355,142 @@ __global__ __launch_bounds__(256, 4) void k_bg_stream(const uint8_t *__restrict_
     uint2 *ring = lds + threadIdx.x;
 #pragma unroll
     for (int q = 0; q < BG_SLOTS; q++) ring[q * 256] = make_uint2(0, 0);
-    BgRegs R;
+    BgRegs<NW> R;
     const Px8 z = {0, 0, 0, 0};
     R.mp = z; R.last = z; R.prev = z;
     for (int i = 0; i < 2; i++) R.t2[i] = z;
-    for (int i = 0; i < 4; i++) { R.t4[i] = z; R.t8[i] = z; }
+    for (int i = 0; i < 4; i++) R.t4[i] = z;
+    for (int i = 0; i < BgWin<NW>::T8N; i++) R.t8[i] = z;
 #pragma unroll
     for (int i = 0; i < 4; i++) R.pf[i] = ld_stream(src + (size_t)(a + i <= kend ? a + i : kend) * P + E.off8);
+    constexpr int U = BgWin<NW>::U;
     int k = a;
-    for (; k + 3 <= kend; k += 4) {                         // branch-free body: counted waits keep 4 loads in flight
-        bg_step<0, PAD>(R, ring, E, src, k, a, kend, n);
-        bg_step<1, PAD>(R, ring, E, src, k + 1, a, kend, n);
-        bg_step<2, PAD>(R, ring, E, src, k + 2, a, kend, n);
-        bg_step<3, PAD>(R, ring, E, src, k + 3, a, kend, n);
-        bg_flush(E, R.acc, k - 11, a, n - 12, 4);           // (step k emits frame k - 11, stored while a <= k - 11 and k < n - 1)
+    // branch-free body: counted waits keep 4 loads in flight.  Step k emits frame k - (NW-1), stored while a <= k - (NW-1)
+    // and k < n - 1 (the frames from n - NW on share one background and follow the loop).
+    if constexpr (U == 8) {
+        for (; k + 7 <= kend; k += 8) {
+            bg_step<0, NW, PAD>(R, ring, E, src, k, a, kend, n);
+            bg_step<1, NW, PAD>(R, ring, E, src, k + 1, a, kend, n);
+            bg_step<2, NW, PAD>(R, ring, E, src, k + 2, a, kend, n);
+            bg_step<3, NW, PAD>(R, ring, E, src, k + 3, a, kend, n);
+            bg_flush(E, R.acc, k - (NW - 1), a, n - NW, 4);
+            bg_step<4, NW, PAD>(R, ring, E, src, k + 4, a, kend, n);
+            bg_step<5, NW, PAD>(R, ring, E, src, k + 5, a, kend, n);
+            bg_step<6, NW, PAD>(R, ring, E, src, k + 6, a, kend, n);
+            bg_step<7, NW, PAD>(R, ring, E, src, k + 7, a, kend, n);
+            bg_flush(E, R.acc, k + 4 - (NW - 1), a, n - NW, 4);
+        }
+        if (k + 3 <= kend) {
+            bg_step<0, NW, PAD>(R, ring, E, src, k, a, kend, n);
+            bg_step<1, NW, PAD>(R, ring, E, src, k + 1, a, kend, n);
+            bg_step<2, NW, PAD>(R, ring, E, src, k + 2, a, kend, n);
+            bg_step<3, NW, PAD>(R, ring, E, src, k + 3, a, kend, n);
+            bg_flush(E, R.acc, k - (NW - 1), a, n - NW, 4);
+            k += 4;
+            if (k <= kend) {
+                const int left = kend - k + 1;              // 1 .. 3 steps
+                bg_step<4, NW, PAD>(R, ring, E, src, k, a, kend, n);
+                if (left > 1) bg_step<5, NW, PAD>(R, ring, E, src, k + 1, a, kend, n);
+                if (left > 2) bg_step<6, NW, PAD>(R, ring, E, src, k + 2, a, kend, n);
+                bg_flush(E, R.acc, k - (NW - 1), a, n - NW, left);
+            }
+        } else if (k <= kend) {
+            const int left = kend - k + 1;
+            bg_step<0, NW, PAD>(R, ring, E, src, k, a, kend, n);
+            if (left > 1) bg_step<1, NW, PAD>(R, ring, E, src, k + 1, a, kend, n);
+            if (left > 2) bg_step<2, NW, PAD>(R, ring, E, src, k + 2, a, kend, n);
+            bg_flush(E, R.acc, k - (NW - 1), a, n - NW, left);
+        }
+    } else {
+        for (; k + 3 <= kend; k += 4) {
+            bg_step<0, NW, PAD>(R, ring, E, src, k, a, kend, n);
+            bg_step<1, NW, PAD>(R, ring, E, src, k + 1, a, kend, n);
+            bg_step<2, NW, PAD>(R, ring, E, src, k + 2, a, kend, n);
+            bg_step<3, NW, PAD>(R, ring, E, src, k + 3, a, kend, n);
+            bg_flush(E, R.acc, k - (NW - 1), a, n - NW, 4);
+        }
+        if (k <= kend) {
+            const int left = kend - k + 1;                  // 1 .. 3 steps
+            bg_step<0, NW, PAD>(R, ring, E, src, k, a, kend, n);
+            if (left > 1) bg_step<1, NW, PAD>(R, ring, E, src, k + 1, a, kend, n);
+            if (left > 2) bg_step<2, NW, PAD>(R, ring, E, src, k + 2, a, kend, n);
+            bg_flush(E, R.acc, k - (NW - 1), a, n - NW, left);
+        }
     }
-    if (k <= kend) {
-        const int left = kend - k + 1;                      // 1 .. 3 steps
-        bg_step<0, PAD>(R, ring, E, src, k, a, kend, n);
-        if (left > 1) bg_step<1, PAD>(R, ring, E, src, k + 1, a, kend, n);
-        if (left > 2) bg_step<2, PAD>(R, ring, E, src, k + 2, a, kend, n);
-        bg_flush(E, R.acc, k - 11, a, n - 12, left);
-    }
-    if (b == n) {                                           // the last 12 frames share bg[n-12] = T11 of the final step;
+    if (b == n) {                                           // the last NW frames share bg[n-NW] = TM of the final step;
 #pragma unroll 1
-        for (int i = n - 12; i < n; i += 4) {                // their raw pixels are still in the ring (a <= n - 12)
+        for (int i = n - NW; i < n; i += 4) {                // their raw pixels are still in the ring (a <= n - NW)
+            const int cnt = n - i < 4 ? n - i : 4;           // (NW = 10, 14: the last group holds two frames)
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const uint2 img = ring[((i + j) & (BG_SLOTS - 1)) * 256];
-                bg_emit<PAD>(E, img, px_split(img), R.last, i + j, true, R.acc.p[j], R.acc.s1[j], R.acc.s3[j]);
+                bg_emit<PAD>(E, img, px_split(img), R.last, i + j, j < cnt, R.acc.p[j], R.acc.s1[j], R.acc.s3[j]);
             }
-            bg_flush(E, R.acc, i, n - 12, n, 4);
+            bg_flush(E, R.acc, i, n - NW, n, cnt);
         }
     }
 }
 
-// detection.py:178-202 for a cleaned image that did not come from k_bg_* (e.g. after deconvolution)
+// detection.py:178-202 for a cleaned image that did not come from k_bg_* (the reference's default path: the deconvolved
+// frame, segmenter.py:243-254): corrected = 255 - cleaned, masked sum / sum of squares, corrected[outside] = 0, the
+// threshold bit plane.  Streaming form, like k_bg_stream: a thread owns one 8-pixel strip (mask bytes, threshold constants
+// and addresses stay in registers) and walks the frames [a, b) of its chunk with four non-temporal loads in flight; the
+// packed byte forms of bg_emit (v_sad_u8 / v_dot4 sums, carry-free byte compare + v_bitop3 for the flags, two dot products
+// to gather them); the per-lane sums of four frames are reduced over the wave at once (rows_of_frames + four row_shr
+// levels) and lanes 15 / 31 / 47 / 63 store them.  No LDS, no barriers.  partials[f][wave] = (0, 0, sum c, sum c^2).
+// Algorithmic traffic: P read + P / 8 written per frame.
+#define THR_FCHUNK 40                                       // frames per block (a multiple of 4)
+template <bool PAD>
 __global__ __launch_bounds__(256) void k_threshold(const uint8_t *__restrict__ cleaned, size_t P, const uint8_t *__restrict__ mask,
-                                                   int thr, uint8_t *__restrict__ bits8, uint32_t *__restrict__ partials)
+                                                   int thr, uint8_t *__restrict__ bits8, uint4 *__restrict__ partials, int n,
+                                                   uint32_t *__restrict__ maskpart)
 {
     size_t strip = (size_t)blockIdx.x * 256 + threadIdx.x;
-    int f = blockIdx.y;
-    uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-    if (strip * 8 < P) {
-        uint2 cl = *(const uint2 *)(cleaned + (size_t)f * P + strip * 8);
-        uint2 corr = make_uint2(~cl.x, ~cl.y);
-        uint2 inm = make_uint2(0xffffffffu, 0xffffffffu);
-        if (mask) { uint2 m = *(const uint2 *)(mask + strip * 8); inm = make_uint2(eq255_4(m.x), eq255_4(m.y)); }
-        uint32_t b = tail4(cl.x, corr.x, inm.x, thr, s0, s1, s2, s3) | (tail4(cl.y, corr.y, inm.y, thr, s0, s1, s2, s3) << 4);
-        bits8[(size_t)f * (P / 8) + strip] = (uint8_t)b;
+    const bool act = !PAD || strip * 8 < P;
+    if (!act) strip = 0;
+    const int a = blockIdx.y * THR_FCHUNK, b = a + THR_FCHUNK < n ? a + THR_FCHUNK : n;
+    const uint32_t off8 = (uint32_t)strip * 8u, strip32 = (uint32_t)strip;
+    uint2 inm = make_uint2(0xffffffffu, 0xffffffffu);
+    if (mask) { const uint2 m = *(const uint2 *)(mask + strip * 8); inm = make_uint2(eq255_4(m.x), eq255_4(m.y)); }
+    if (!act) inm = make_uint2(0u, 0u);
+    const int t1 = thr + 1 > 0 ? thr + 1 : 0;               // pixel > thr  <=>  pixel >= thr + 1 (see bg_emit)
+    const bool thr_ok = t1 <= 255;
+    const uint32_t kadd = (uint32_t)(t1 <= 128 ? 128 - t1 : 256 - (t1 > 255 ? 255 : t1)) * 0x01010101u;
+    const uint32_t lowm = t1 <= 128 ? 0xffffffffu : 0u;
+    const uint2 m80 = thr_ok ? make_uint2(inm.x & 0x80808080u, inm.y & 0x80808080u) : make_uint2(0u, 0u);
+    const uint32_t nwaves = gridDim.x * 4, wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (mask && blockIdx.y == 0) {                           // pixels with mask == 255, per wave (summed by k_reduce_partials)
+        const uint32_t mc = wave_sum63((uint32_t)__popc(gather4(inm.x & 0x80808080u) | (gather4(inm.y & 0x80808080u) << 4)));
+        if (lane == 63) maskpart[wave] = mc;
     }
-    block_sum4_store(s0, s1, s2, s3, partials + ((size_t)f * gridDim.x + blockIdx.x) * 4);
+    uint2 pf[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) pf[i] = ld_stream_at(cleaned + (size_t)(a + i < b ? a + i : b - 1) * P, off8);
+    for (int k = a; k < b; k += 4) {
+        uint32_t ps[4], qs[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint2 cl = pf[j];
+            const int kn = k + 4 + j < b ? k + 4 + j : b - 1;        // clamped prefetch: always a valid frame
+            pf[j] = ld_stream_at(cleaned + (size_t)kn * P, off8);
+            const uint2 corr = make_uint2(~cl.x, ~cl.y);             // detection.py:178
+            const uint2 cm = make_uint2(corr.x & inm.x, corr.y & inm.y);
+            ps[j] = __builtin_amdgcn_sad_u8(cm.x, 0u, __builtin_amdgcn_sad_u8(cm.y, 0u, 0u));
+            qs[j] = __builtin_amdgcn_udot4(cm.x, cm.x, __builtin_amdgcn_udot4(cm.y, cm.y, 0u, false), false);
+            const uint32_t t0 = (corr.x & 0x7f7f7f7fu) + kadd, t1v = (corr.y & 0x7f7f7f7fu) + kadd;
+            const uint32_t f0 = __builtin_amdgcn_bitop3_b32(t0, corr.x, lowm, 0xE8) & m80.x, f1 = __builtin_amdgcn_bitop3_b32(t1v, corr.y, lowm, 0xE8) & m80.y;
+            const uint32_t bb = __builtin_amdgcn_udot4(f1, 0x80402010u, __builtin_amdgcn_udot4(f0, 0x08040201u, 0u, false), false) >> 7;
+            if (k + j < b && act)                                    // (wave-uniform but for the padding lanes of the last block)
+                __builtin_amdgcn_raw_buffer_store_b8((uint8_t)bb, raw_rsrc(bits8 + (size_t)(k + j) * (P / 8)), (int)strip32, 0, 0);
+        }
+        uint32_t p = rows_of_frames(ps[0], ps[1], ps[2], ps[3]);     // row r of the wave: frame k + r
+        uint32_t q = rows_of_frames(qs[0], qs[1], qs[2], qs[3]);
+        p = dpp_add<0x111, 0xf>(p); p = dpp_add<0x112, 0xf>(p); p = dpp_add<0x114, 0xf>(p); p = dpp_add<0x118, 0xf>(p);
+        q = dpp_add<0x111, 0xf>(q); q = dpp_add<0x112, 0xf>(q); q = dpp_add<0x114, 0xf>(q); q = dpp_add<0x118, 0xf>(q);
+        const int fr = k + (lane >> 4);
+        if ((lane & 15) == 15 && fr < b) partials[(size_t)fr * nwaves + wave] = make_uint4(0u, 0u, p, q);
+    }
 }
 
 // per-frame reduction of the block partials; fsums[f*4+k] u64.  If setvalid: valid[f] = std > 2,

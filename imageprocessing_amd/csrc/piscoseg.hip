@@ -95,6 +95,8 @@ struct pseg_ctx {
     struct GpuTurn *turn = nullptr;
     int bg_chunks = 1;            // time chunks of the streaming background kernel (PSEG_BG_CHUNKS)
     int bg_resident = 0;          // blocks of the streaming background kernel the device holds at once (0: no tail split)
+    bool bg_resident_forced = false;
+    int last_bg_stream = -1;      // the last background call took the streaming kernel (1) / the re-reading one (0): pseg_tuning_state 6
     int bounds_tailk = -1;
     bool force_generic = false;   // PSEG_BG_GENERIC=1: use the 12x-read reference kernel (debug / cross-check)
     bool no_bands = false;        // PSEG_NO_BANDS=1: label with the global union-find only (the path of very dense frames)
@@ -239,7 +241,7 @@ extern "C" int pseg_create(int device, int H, int W, int max_frames, pseg_ctx **
     {
         hipDeviceProp_t prop;                                // 4 blocks per CU (the kernel's launch bounds): see run_bg
         if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->bg_resident = 4 * prop.multiProcessorCount;
-        if (const char *e = getenv("PSEG_BG_TAIL")) ctx->bg_resident = atoi(e) > 0 ? atoi(e) : 0;   // 0: off, N: pretend N slots
+        if (const char *e = getenv("PSEG_BG_TAIL")) { ctx->bg_resident = atoi(e) > 0 ? atoi(e) : 0; ctx->bg_resident_forced = true; }   // 0: off, N: pretend N slots
     }
     if (const char *e = getenv("PSEG_EXCLUSIVE")) ctx->exclusive = atoi(e) != 0;
     if (const char *e = getenv("PSEG_EARLY_RELEASE")) ctx->early_release = atoi(e) != 0;
@@ -307,6 +309,7 @@ extern "C" long long pseg_tuning_state(const pseg_ctx *ctx, int which)
     case 3: return ctx->fill_rows >= 0 ? (ctx->fill_rows > 0) : (ctx->dense_rows ? 1 : 0);
     case 4: return ctx->band_order;
     case 5: return ctx->band_fallbacks;
+    case 6: return ctx->last_bg_stream;
     default: return -1;
     }
 }
@@ -439,7 +442,11 @@ static int run_bg(pseg_ctx *ctx, const uint8_t *frames, int n_avail, int n_emit,
     const int n_kernel = part ? n_avail + 1 : n_avail;       // batch length as the kernels see it
     size_t P = ctx->P;
     unsigned nblk = nblocks(P / 8);
-    const bool stream = (NW == 12 && last_len >= 12 && (!batch_len || batch_len >= 12) && !ctx->force_generic);
+    // streaming kernel: instantiated for windows of 8, 10, 12 and 16 frames (n_bg_imgs = 4, 5, 6 -- the reference's -- and 8);
+    // other windows, and batches shorter than one window, take the kernel that re-reads the window per frame
+    const bool stream = ((NW == 8 || NW == 10 || NW == 12 || NW == 16) && last_len >= NW && (!batch_len || batch_len >= NW) &&
+                         !ctx->force_generic);
+    ctx->last_bg_stream = stream ? 1 : 0;
     unsigned npart = stream ? nblk * 4 : nblk;               // partial sums per frame: per wave / per block
     ENSURE(ctx->bits, (size_t)n * P / 8);
     ENSURE(ctx->partials, (size_t)n * npart * 4 * sizeof(uint32_t));
@@ -458,7 +465,7 @@ static int run_bg(pseg_ctx *ctx, const uint8_t *frames, int n_avail, int n_emit,
             bnd[chunks] = n_avail;
         } else {
             chunks = ctx->bg_chunks;
-            const int span = part ? n_emit : n_avail - 12;    // chunk starts lie in [0, span)
+            const int span = part ? n_emit : n_avail - NW;    // chunk starts lie in [0, span)
             if (chunks > span) chunks = span;
             if (chunks < 1) chunks = 1;
             bnd.resize(2 * chunks + 1);
@@ -469,12 +476,12 @@ static int run_bg(pseg_ctx *ctx, const uint8_t *frames, int n_avail, int n_emit,
             // tailk blocks each, which walk tailk shorter time ranges (11 halo frames more per range), so that the device
             // stays filled to the end: 0.611 -> 0.585 ms.  Measured level (0.584 - 0.592 ms): 2944 - 3072 whole strips with
             // the rest shared by 3 - 7 blocks; 2560 whole strips and 2 - 7 blocks for the rest: 0.591 - 0.605 ms.
-            const int res = ctx->bg_resident;
+            const int res = NW > 12 && !ctx->bg_resident_forced ? ctx->bg_resident / 4 * 3 : ctx->bg_resident;   // (BgWin<NW>::BLOCKS per CU)
             if (chunks == 1 && res > 0 && nblk > (unsigned)res && nblk % res) {
                 const unsigned rem = nblk % res;
                 tailk = (int)(res / rem);
                 if (tailk > 4) tailk = 4;
-                if (tailk > span / 24) tailk = span / 24;
+                if (tailk > span / (2 * NW)) tailk = span / (2 * NW);
                 if (tailk > 1) {
                     nfull = nblk - rem;
                     for (int c = 0; c < tailk; c++) bnd.push_back((int)((long long)c * span / tailk));
@@ -492,14 +499,20 @@ static int run_bg(pseg_ctx *ctx, const uint8_t *frames, int n_avail, int n_emit,
         }
     }
     TIMED_RECORD(0);
-    if (stream && P % 2048 == 0)
-        hipLaunchKernelGGL(k_bg_stream<false>, dim3(nfull + (nblk - nfull) * tailk, chunks), dim3(256), 0, ctx->cur, frames, P, cleaned,
-                           mask, thr, (uint8_t *)ctx->bits.p, (uint4 *)ctx->partials.p, (const int *)ctx->bounds.p, (uint8_t *)ctx->trash.p,
-                           (uint32_t *)ctx->maskpart.p, (int)nfull, tailk);
-    else if (stream)
-        hipLaunchKernelGGL(k_bg_stream<true>, dim3(nfull + (nblk - nfull) * tailk, chunks), dim3(256), 0, ctx->cur, frames, P, cleaned,
-                           mask, thr, (uint8_t *)ctx->bits.p, (uint4 *)ctx->partials.p, (const int *)ctx->bounds.p, (uint8_t *)ctx->trash.p,
-                           (uint32_t *)ctx->maskpart.p, (int)nfull, tailk);
+    if (stream) {
+        const dim3 grid(nfull + (nblk - nfull) * tailk, chunks);
+#define BG_LAUNCH(NW_, PAD_) hipLaunchKernelGGL((k_bg_stream<NW_, PAD_>), grid, dim3(256), 0, ctx->cur, frames, P, cleaned, mask, thr,       \
+                                                (uint8_t *)ctx->bits.p, (uint4 *)ctx->partials.p, (const int *)ctx->bounds.p,                \
+                                                (uint8_t *)ctx->trash.p, (uint32_t *)ctx->maskpart.p, (int)nfull, tailk)
+        const bool pad = P % 2048 != 0;
+        switch (NW) {
+        case 8: if (pad) BG_LAUNCH(8, true); else BG_LAUNCH(8, false); break;
+        case 10: if (pad) BG_LAUNCH(10, true); else BG_LAUNCH(10, false); break;
+        case 16: if (pad) BG_LAUNCH(16, true); else BG_LAUNCH(16, false); break;
+        default: if (pad) BG_LAUNCH(12, true); else BG_LAUNCH(12, false); break;
+        }
+#undef BG_LAUNCH
+    }
     else
         for (int c = 0; c < nbatch; c++) {                   // the re-reading kernel takes one batch per launch
             const size_t f0 = (size_t)c * (batch_len ? batch_len : 0);
@@ -1005,22 +1018,29 @@ extern "C" int pseg_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t 
     if (!raw) raw = cleaned;
     size_t P = ctx->P;
     unsigned nblk = nblocks(P / 8);
+    const unsigned npart = nblk * 4;                         // partial sums per frame: one uint4 per wave
     ENSURE(ctx->bits, (size_t)n * P / 8);
-    ENSURE(ctx->partials, (size_t)n * nblk * 4 * sizeof(uint32_t));
+    ENSURE(ctx->partials, (size_t)n * npart * 4 * sizeof(uint32_t));
+    ENSURE(ctx->maskpart, (size_t)npart * 4 + 16);
     { int r_ = head_setup(ctx, n); if (r_) return r_; }
     GpuTurn turn(ctx);
     TIMED_RECORD(6);
     if (valid) HIPCHK(hipMemcpyAsync(ctx->valid_dev.p, valid, n, hipMemcpyHostToDevice, ctx->cur));
     else HIPCHK(hipMemsetAsync(ctx->valid_dev.p, 1, n, ctx->cur));
     TIMED_RECORD(0);
-    hipLaunchKernelGGL(k_threshold, dim3(nblk, n), dim3(256), 0, ctx->cur, cleaned, P, mask, threshold, (uint8_t *)ctx->bits.p,
-                       (uint32_t *)ctx->partials.p);
+    {
+        const dim3 grid(nblk, (n + THR_FCHUNK - 1) / THR_FCHUNK);
+        if (P % 2048 == 0)
+            hipLaunchKernelGGL(k_threshold<false>, grid, dim3(256), 0, ctx->cur, cleaned, P, mask, threshold, (uint8_t *)ctx->bits.p, (uint4 *)ctx->partials.p, n, (uint32_t *)ctx->maskpart.p);
+        else
+            hipLaunchKernelGGL(k_threshold<true>, grid, dim3(256), 0, ctx->cur, cleaned, P, mask, threshold, (uint8_t *)ctx->bits.p, (uint4 *)ctx->partials.p, n, (uint32_t *)ctx->maskpart.p);
+    }
     HIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(k_reduce_partials, dim3(n), dim3(1024), 0, ctx->cur, (const uint32_t *)ctx->partials.p, (int)nblk,
+    hipLaunchKernelGGL(k_reduce_partials, dim3(n), dim3(1024), 0, ctx->cur, (const uint32_t *)ctx->partials.p, (int)npart,
                        (unsigned long long)P, (unsigned long long *)ctx->fsums.p, (uint8_t *)ctx->valid_dev.p, 0, 2, 2,
-                       (unsigned long long *)ctx->maskcnt.p, (uint32_t *)ctx->framebase.p + n + 1, (const uint32_t *)nullptr, 0,
-                       (unsigned long long *)ctx->scan_state.p, scan_words(ctx, n));
-    ctx->mask_counted = false;
+                       (unsigned long long *)ctx->maskcnt.p, (uint32_t *)ctx->framebase.p + n + 1, (const uint32_t *)ctx->maskpart.p,
+                       mask ? (int)npart : 0, (unsigned long long *)ctx->scan_state.p, scan_words(ctx, n));
+    ctx->mask_counted = mask != nullptr;                     // (k_threshold left per-wave counts of the mask pixels)
     HIPCHK(hipGetLastError());
     TIMED_RECORD(1);
     r = run_detect(ctx, cleaned, raw, mask, n, min_area_to_segment, min_area_to_save, labels, out);

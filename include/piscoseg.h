@@ -203,7 +203,8 @@ float pseg_last_ms(const pseg_ctx *ctx, int which);
  * a context moves to for good after a scan in index order timed out -- the batch is repeated inside the call; environment
  * PSEG_BAND_ORDER=0 starts there, and so do contexts that take no turns, PSEG_EXCLUSIVE=0; several processes sharing one GPU
  * should set it: their band kernels can block each other in index order until the bound, about 0.1 s, ends it),
- * 5 = times that has happened.
+ * 5 = times that has happened, 6 = 1 when the last background correction ran the streaming kernel (windows of 8, 10, 12, 16
+ * frames in batches of at least one window), 0 the kernel that re-reads the window per frame, -1 before the first call.
  * Returns -1 for a bad argument. */
 long long pseg_tuning_state(const pseg_ctx *ctx, int which);
 

@@ -254,24 +254,32 @@ def test_rows_wider_than_one_wave_of_words(gpu_seg_factory):
         assert tab2.frame_n_contours[i] == len(helpers.cv_ref.findContours(thr.astype(np.uint8), 0, 2)[0])
 
 
-@pytest.mark.parametrize("n_bg_imgs,n,generic", [(2, 9, "0"), (8, 20, "0"), (3, 16, "0"), (6, 30, "1")])
-def test_other_windows_and_the_generic_kernel(monkeypatch, n_bg_imgs, n, generic):
-    """Windows other than the reference's 12 frames (bg_size = 6) and PSEG_BG_GENERIC=1 take the re-reading kernel; the
-    fused path, its masked statistics and the part / halo form must agree with the oracle there too."""
+@pytest.mark.parametrize("n_bg_imgs,n,generic,shape", [
+    (2, 9, "0", (64, 128)), (3, 16, "0", (64, 128)), (7, 40, "0", (64, 128)),                       # windows without a streaming form
+    (4, 8, "0", (64, 128)), (4, 31, "0", (64, 128)), (5, 10, "0", (64, 128)), (5, 33, "0", (64, 128)), (5, 47, "0", (40, 64)),
+    (8, 16, "0", (64, 128)), (8, 20, "0", (64, 128)), (8, 45, "0", (64, 128)), (8, 61, "0", (40, 64)), (6, 41, "0", (40, 64)),
+    (5, 33, "1", (64, 128)), (8, 45, "1", (64, 128)), (6, 30, "1", (64, 128))])                     # the re-reading kernel as cross-check
+def test_other_windows_and_the_generic_kernel(monkeypatch, n_bg_imgs, n, generic, shape):
+    """Windows other than the reference's 12 frames (bg_size = 6): 8, 10 and 16 frames (n_bg_imgs 4, 5, 8) have a streaming
+    kernel of their own (another last combination of the sparse table, a deeper T8 history for 16), every other window
+    and PSEG_BG_GENERIC=1 take the re-reading kernel; the fused path, its masked statistics and the part / halo form must
+    agree with the oracle in all of them.  40 x 64: P is no multiple of 2048 (padding lanes)."""
     import torch
     from imageprocessing_amd.engine import Segmenter
     monkeypatch.setenv("PSEG_BG_GENERIC", generic)
-    H, W = 64, 128
+    H, W = shape
     seg = Segmenter(H, W, max_frames=n, device=0)
     rng = np.random.default_rng(7 * n_bg_imgs + n)
     stack = rng.integers(0, 256, (n, H, W), dtype=np.uint8)
-    mask = helpers.make_disk(H, W, 28)
+    mask = helpers.make_disk(H, W, min(H, W) // 2 - 4)
     images = [(stack[i], f"img_{i:05d}.png") for i in range(n)]
     items = [helpers.ref.correct_img(i, images, n_bg_imgs) for i in range(n)]
     dev, dmask = torch.from_numpy(stack).cuda(), torch.from_numpy(mask).cuda()
     cleaned, ms, valid, tab = seg.process(dev, n_bg_imgs=n_bg_imgs, mask=dmask, threshold=90)
+    assert seg.tuning_state()["bg_streaming"] == (1 if generic == "0" and n_bg_imgs in (4, 5, 6, 8) else 0)
     cl = cleaned.cpu().numpy()
     for i, it in enumerate(items):
+        np.testing.assert_allclose(ms[i], it[2], rtol=1e-9, atol=1e-9)
         assert np.array_equal(cl[i], it[1]), f"frame {i}"
         corr = (255 - it[1])[mask == 255]
         np.testing.assert_allclose([tab.frame_mean[i], tab.frame_std[i]], [corr.mean(), corr.std()], rtol=1e-9)
