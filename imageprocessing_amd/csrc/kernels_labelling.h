@@ -662,10 +662,76 @@ __global__ __launch_bounds__(256) void k_scan_small(const uint32_t *in, uint32_t
     if (threadIdx.x == 0) out[(size_t)F * stride_out] = carry;
 }
 
+#define RANK_IPT 4
+// Label-map values before the table exists.  The label of a run is the 1-based OpenCV index of its external contour =
+// (external roots of the frame) - (rank of its root among them), and needs neither areas nor boxes: this kernel ranks the
+// external roots of every frame (block per frame, as k_rank) and then writes runlabel for the frame's runs, so that the label
+// fill can follow the enclosure tree directly and bbox / area / ranks / rows / size scans run BEHIND the fill, beside the next
+// batch's background kernel (they were 67 us of the batch's critical path, 0.44 ms on frames of 2000 objects).
+// ftot3[f*3] = number of external contours.
+__global__ __launch_bounds__(1024) void k_rank_ext(SegState S, uint32_t *ftot3, int32_t *__restrict__ runlabel, uint32_t cap, uint32_t bcap)
+{
+    __shared__ uint32_t wtot[16];
+    __shared__ uint32_t carry;
+    if (!chain_ok(S, cap, bcap)) return;
+    const int f = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int r0 = (int)S.framebase[f], r1 = (int)S.framebase[f + 1];
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = r0; base < r1; base += 1024 * RANK_IPT) {
+        const int r = base + RANK_IPT * (int)threadIdx.x;
+        const bool full = r + RANK_IPT <= r1;
+        int fp[RANK_IPT], ex[RANK_IPT];
+        if (full) { __builtin_memcpy(fp, S.fg_parent + r, 4 * RANK_IPT); __builtin_memcpy(ex, S.ext + r, 4 * RANK_IPT); }
+        else
+#pragma unroll
+            for (int j = 0; j < RANK_IPT; j++) { fp[j] = r + j < r1 ? S.fg_parent[r + j] : -1; ex[j] = r + j < r1 ? S.ext[r + j] : -1; }
+        uint32_t m0 = 0;                                     // bit j: run r + j is an external root
+#pragma unroll
+        for (int j = 0; j < RANK_IPT; j++) m0 |= (uint32_t)(fp[j] == r + j && ex[j] == r + j) << j;
+        const uint32_t cnt = (uint32_t)__popc(m0);
+        const uint32_t incl = wave_scan_incl(cnt);
+        if (lane == 63) wtot[wv] = incl;
+        __syncthreads();
+        uint32_t p0 = carry;
+        for (int w = 0; w < wv; w++) p0 += wtot[w];
+        const uint32_t excl = p0 + incl - cnt;
+#pragma unroll
+        for (int j = 0; j < RANK_IPT; j++)
+            if ((m0 >> j) & 1u)                             // (only roots are ever looked up; stored past the L1 cache: see below)
+                __hip_atomic_store(S.extrank + r + j, (int)(excl + (uint32_t)__popc(m0 & ((1u << j) - 1u))), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = p0 + incl;
+        __syncthreads();
+    }
+    const int next = (int)carry;
+    if (threadIdx.x == 0) ftot3[f * 3] = (uint32_t)next;
+    // The ranks written above are read back by other threads of this block.  No fence (an agent-scope fence writes the whole
+    // L2 of the XCD back: the kernel took 57 us with one): the stores above and the loads below are relaxed agent-scope
+    // atomics, which pass the L1 cache both ways, and the barrier waits for the stores' acknowledgements.
+    __syncthreads();
+    for (int base = r0; base < r1; base += 1024 * RANK_IPT) {
+        const int r = base + RANK_IPT * (int)threadIdx.x;
+        if (r >= r1) break;
+        const bool full = r + RANK_IPT <= r1;
+        int fp[RANK_IPT], ex[RANK_IPT], lab[RANK_IPT];
+        if (full) { __builtin_memcpy(fp, S.fg_parent + r, 4 * RANK_IPT); __builtin_memcpy(ex, S.ext + r, 4 * RANK_IPT); }
+        else
+#pragma unroll
+            for (int j = 0; j < RANK_IPT; j++) { fp[j] = r + j < r1 ? S.fg_parent[r + j] : -1; ex[j] = r + j < r1 ? S.ext[r + j] : -2; }
+        // label of the run's external component, 0 for components nested in holes (their root is not the external one)
+#pragma unroll
+        for (int j = 0; j < RANK_IPT; j++) lab[j] = (fp[j] == ex[j]) ? next - __hip_atomic_load(S.extrank + ex[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;   // ... and are read from there
+        if (full) __builtin_memcpy(runlabel + r, lab, 4 * RANK_IPT);
+        else
+#pragma unroll
+            for (int j = 0; j < RANK_IPT; j++) if (r + j < r1) runlabel[r + j] = lab[j];
+    }
+}
+
 // ranks of external roots / kept / saved objects inside each frame (block per frame; a thread takes RANK_IPT consecutive
 // runs per round, the three counts of a thread travel through the wave scan packed in one register).
 // ftot3[f*3+{0,1,2}] = number of external contours, kept, saved.
-#define RANK_IPT 4
 __global__ __launch_bounds__(1024) void k_rank(SegState S, double min_seg, double min_save, uint32_t *ftot3, uint32_t cap, uint32_t bcap)
 {
     __shared__ uint32_t wtot[16];                         // per wave: the three totals, 10 bits each (<= 64 * RANK_IPT)

@@ -47,7 +47,7 @@ __host__ __device__ inline int crop_rows_per_band(int w)
 // one row per kept object, ordered (frame, c); c counts from the LAST external root (detection.py:222)
 __global__ void k_emit(SegState S, uint32_t cap, uint32_t bcap, double min_seg, double min_save, const uint32_t *ftot3,
                        const uint32_t *rowbase, const uint32_t *savedbase, RowsDev R, int32_t *objlabel, int32_t *objflag,
-                       int32_t *saved_row, int32_t *runlabel, int32_t *geo, unsigned long long *sz, size_t szstride)
+                       int32_t *saved_row, int32_t *geo, unsigned long long *sz, size_t szstride)
 {
     if (!chain_ok(S, cap, bcap)) return;
     const int nfg = (int)S.framebase[S.F];
@@ -57,10 +57,7 @@ __global__ void k_emit(SegState S, uint32_t cap, uint32_t bcap, double min_seg, 
     objflag[r] = 0;
     objlabel[r] = 0;
     int f = (int)(S.run_fy[r] >> 16);
-    {   // label-map value of this run: the label of its external component, 0 for components nested in holes
-        const int E = S.ext[r];
-        runlabel[r] = (S.fg_parent[r] == E) ? (int)ftot3[f * 3] - S.extrank[E] : 0;
-    }
+    // (the label-map value of the run, runlabel[r], was written by k_rank_ext ahead of the label fill)
     if (!is_ext_root(S, r)) return;
     int next = (int)ftot3[f * 3], nkept = (int)ftot3[f * 3 + 1], nsaved = (int)ftot3[f * 3 + 2];
     int label = next - S.extrank[r];

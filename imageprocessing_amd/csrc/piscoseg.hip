@@ -57,8 +57,14 @@ struct pseg_ctx {
     hipEvent_t ev_turn = nullptr; // recorded behind the streaming part on the shared stream; the own stream waits for it
     bool own_stream = false;
     std::string err;
-    hipEvent_t ev[9] = {};         // 0..7 time the kernel groups, 8 marks the run count on its way to the host
-    float ms[6] = {};
+    hipEvent_t ev[11] = {};        // 0..7 time the kernel groups, 8 marks the run count / the head on its way to the host,
+                                   // 9..10 time the table kernels on the side stream
+    float ms[7] = {};
+    hipStream_t side = nullptr;   // the table kernels (boxes, areas, ranks, rows, size scans) run here, beside the label fill
+    hipEvent_t ev_a = nullptr;    // recorded on the main stream behind the enclosure tree: the side stream waits for it
+    int table_mode = -1;          // where the table kernels run: 0 = before the label fill (the order of rounds 1 and 2), 1 = beside it on
+                                  // the side stream, 2 = behind it, beside the next batch's background kernel; -1 (default) = 1 for
+                                  // ordinary batches, 2 for dense ones (PSEG_TABLE_MODE; a caller's stream or the shared stream: 0 for 1)
     // dense workspaces
     DevBuf bits, partials, maskpart, rowspans;
     // head arena: every small per-frame table the host needs, contiguous so that ONE copy fetches it.
@@ -236,6 +242,14 @@ extern "C" int pseg_create(int device, int H, int W, int max_frames, pseg_ctx **
     // (a failed lookup only means "no no-alloc entry point on this device": pseg_regionprops_noalloc says so by itself)
     (void)rp_static_lookup(device);
     if (hipHostMalloc(&ctx->pin_rp.p, 256, hipHostMallocDefault) == hipSuccess) ctx->pin_rp.bytes = 256; else ctx->pin_rp.p = nullptr;
+    {
+        // (normal priority: with a high-priority side stream a call hung in hipEventSynchronize as soon as a handful of
+        // contexts -- two streams each on the process's four hardware queues -- were alive; the same sequence at normal
+        // priority runs, profiles/tools/r3_hang_probe.sh)
+        if (hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) != hipSuccess) ctx->side = nullptr;
+        if (hipEventCreateWithFlags(&ctx->ev_a, hipEventDisableTiming) != hipSuccess) ctx->ev_a = nullptr;
+        if (const char *e = getenv("PSEG_TABLE_MODE")) ctx->table_mode = atoi(e) >= 0 && atoi(e) <= 2 ? atoi(e) : -1;
+    }
     if (const char *e = getenv("PSEG_BG_CHUNKS")) ctx->bg_chunks = atoi(e) > 0 ? atoi(e) : 1;
     if (const char *e = getenv("PSEG_BG_GENERIC")) ctx->force_generic = atoi(e) != 0;
     {
@@ -292,13 +306,15 @@ extern "C" int pseg_destroy(pseg_ctx *ctx)
     for (PinBuf *b : {&ctx->pin_head, &ctx->pin_tail, &ctx->pin_nfg, &ctx->pin_rp}) if (b->p) hipHostFree(b->p);
     for (auto &e : ctx->ev) if (e) hipEventDestroy(e);
     if (ctx->ev_turn) hipEventDestroy(ctx->ev_turn);
+    if (ctx->ev_a) hipEventDestroy(ctx->ev_a);
+    if (ctx->side) hipStreamDestroy(ctx->side);
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
     return PSEG_OK;
 }
 
 extern "C" const char *pseg_last_error(const pseg_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
-extern "C" float pseg_last_ms(const pseg_ctx *ctx, int which) { return (ctx && which >= 0 && which < 6) ? ctx->ms[which] : -1.f; }
+extern "C" float pseg_last_ms(const pseg_ctx *ctx, int which) { return (ctx && which >= 0 && which < 7) ? ctx->ms[which] : -1.f; }
 extern "C" long long pseg_tuning_state(const pseg_ctx *ctx, int which)
 {
     if (!ctx) return -1;
@@ -544,10 +560,10 @@ static void finish_meanstd(const uint64_t *s, double cnt, double *mean, double *
     *std_ = sqrt(var < 0 ? 0 : var);
 }
 
-static int fetch_head(pseg_ctx *ctx)
+static int fetch_head(pseg_ctx *ctx, hipStream_t st = nullptr)
 {
     HIPCHK(hipMemcpyAsync(ctx->pin_head.p, (const char *)ctx->head.p + ctx->head_copy_off, ctx->head_copy_bytes,
-                          hipMemcpyDeviceToHost, ctx->cur));
+                          hipMemcpyDeviceToHost, st ? st : ctx->cur));
     return 0;
 }
 
@@ -738,25 +754,31 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
 #undef BAND_LAUNCH
         if (H > BAND_H) hipLaunchKernelGGL(k_unions_rows, dim3((H - 1) / BAND_H, n), dim3(64), 0, ctx->cur, S, BAND_H, capv, (uint32_t)ctx->band_cap);
     };
-    // from the flattening to the size scans; gridded for `runs` runs, guarded by (cap, bcap) on the device
-    auto launch_chain = [&](size_t runs, uint32_t capv, uint32_t bcap) {
+    // The chain behind the band labelling comes in two parts.  Part A is what the label map needs: the enclosure tree and the
+    // labels of the runs (k_rank_ext).  Part B -- boxes, areas, ranks, rows, size scans: the table -- is queued BEHIND the label
+    // fill, after the GPU's turn has been handed on, and runs beside the next batch's background kernel.  Both are gridded for
+    // `runs` runs and guarded by (cap, bcap) on the device.
+    auto launch_chain_a = [&](size_t runs, uint32_t capv, uint32_t bcap) {
         const size_t nbgr = runs + (size_t)n * H;
         hipLaunchKernelGGL(k_flatten_resolve, dim3(nblocks(nbgr)), dim3(256), 0, ctx->cur, S, capv, bcap);
+        hipLaunchKernelGGL(k_rank_ext, dim3(n), dim3(1024), 0, ctx->cur, S, ftot3, (int32_t *)ctx->runlabel.p, capv, bcap);
+    };
+    auto launch_chain_b = [&](hipStream_t st, size_t runs, uint32_t capv, uint32_t bcap) {
         if (runs > 0) {
-            hipLaunchKernelGGL(k_bbox, dim3(nblocks(runs)), dim3(256), 0, ctx->cur, S, capv, bcap);
-            hipLaunchKernelGGL(k_area, dim3(nblocks(runs)), dim3(256), 0, ctx->cur, S, capv, bcap);
+            hipLaunchKernelGGL(k_bbox, dim3(nblocks(runs)), dim3(256), 0, st, S, capv, bcap);
+            hipLaunchKernelGGL(k_area, dim3(nblocks(runs)), dim3(256), 0, st, S, capv, bcap);
         }
-        hipLaunchKernelGGL(k_rank, dim3(n), dim3(1024), 0, ctx->cur, S, min_seg, min_save, ftot3, capv, bcap);
-        hipLaunchKernelGGL(k_scan_small, dim3(2), dim3(256), 0, ctx->cur, (const uint32_t *)(ftot3 + 1), rowbase, n, 3, 1);   // rowbase | savedbase
+        hipLaunchKernelGGL(k_rank, dim3(n), dim3(1024), 0, st, S, min_seg, min_save, ftot3, capv, bcap);
+        hipLaunchKernelGGL(k_scan_small, dim3(2), dim3(256), 0, st, (const uint32_t *)(ftot3 + 1), rowbase, n, 3, 1);   // rowbase | savedbase
         if (runs > 0)
-            hipLaunchKernelGGL(k_emit, dim3(nblocks(runs)), dim3(256), 0, ctx->cur, S, capv, bcap, min_seg, min_save, (const uint32_t *)ftot3,
+            hipLaunchKernelGGL(k_emit, dim3(nblocks(runs)), dim3(256), 0, st, S, capv, bcap, min_seg, min_save, (const uint32_t *)ftot3,
                                (const uint32_t *)rowbase, (const uint32_t *)savedbase, R, objlabel, objflag, saved_row,
-                               (int32_t *)ctx->runlabel.p, geo, sz, sz_stride(rcap));
+                               geo, sz, sz_stride(rcap));
         const int scan_blocks = ctx->n_saved > ctx->scan_multi_min ? SCAN_BLOCKS : 1;      // (by the previous batch)
         if (scan_blocks > 1)
-            hipLaunchKernelGGL(k_scan_sizes_part, dim3(scan_blocks), dim3(1024), 0, ctx->cur, S, capv, bcap, (const unsigned long long *)sz, sz_stride(rcap),
+            hipLaunchKernelGGL(k_scan_sizes_part, dim3(scan_blocks), dim3(1024), 0, st, S, capv, bcap, (const unsigned long long *)sz, sz_stride(rcap),
                                (const uint32_t *)(savedbase + n), (unsigned long long *)ctx->scan_part.p);
-        hipLaunchKernelGGL(k_scan_sizes, dim3(scan_blocks), dim3(1024), 0, ctx->cur, S, capv, bcap, (const unsigned long long *)sz, sz_stride(rcap),
+        hipLaunchKernelGGL(k_scan_sizes, dim3(scan_blocks), dim3(1024), 0, st, S, capv, bcap, (const unsigned long long *)sz, sz_stride(rcap),
                            (const uint32_t *)(savedbase + n), (long long *)ctx->crop_off.p, (long long *)ctx->bits_off.p,
                            (long long *)ctx->band_off.p, totals, (const unsigned long long *)ctx->scan_part.p);
     };
@@ -791,10 +813,11 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
     int nfg = 0;
     uint32_t band_seen = 0;
     for (;;) {
+        size_t chain_runs; uint32_t chain_cap, chain_bcap;   // part B is queued with what part A was queued with
         if (spec) {
             { int r_ = ensure_tables(ctx->runcap); if (r_) return r_; }
             launch_fused((uint32_t)ctx->runcap);
-            launch_chain(ctx->runcap, (uint32_t)ctx->runcap, (uint32_t)ctx->band_cap);
+            chain_runs = ctx->runcap; chain_cap = (uint32_t)ctx->runcap; chain_bcap = (uint32_t)ctx->band_cap;
         } else {
             { int r_ = ensure_tables(ctx->runcap > 0 ? ctx->runcap : 1); if (r_) return r_; }
             const uint32_t cap0 = fused && ctx->runcap > 0 ? (uint32_t)ctx->runcap : 0u;
@@ -842,12 +865,37 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
                 hipLaunchKernelGGL(k_init, dim3(nblocks(nbg)), dim3(256), 0, ctx->cur, S, nfg, nbg);
                 hipLaunchKernelGGL(k_unions, dim3(nblocks(nbg)), dim3(256), 0, ctx->cur, S, nfg, nbg, 0);
             }
-            launch_chain((size_t)nfg, 0xffffffffu, 0xffffffffu);
+            chain_runs = (size_t)nfg; chain_cap = 0xffffffffu; chain_bcap = 0xffffffffu;
         }
+        launch_chain_a(chain_runs, chain_cap, chain_bcap);
         HIPCHK(hipGetLastError());
-        // per-frame tables and totals to the host (one copy of the head arena); the label map is written while the host waits
-        { int r_ = fetch_head(ctx); if (r_) return r_; }
-        HIPCHK(hipEventRecord(ctx->ev[3], ctx->cur));
+        // where the table kernels go (ctx->table_mode): beside the label fill needs the context's own streams
+        // Measured on one box (profiles/r03/10_table_modes.txt), frames/s of the 2000-frame stacks with 3 contexts:
+        //   ordinary frames (3 runs per row):  before 98 300 - 99 600, beside 105 400 - 106 000, behind 101 200
+        //   2000 objects per frame (19 runs per row, 440 us of table kernels):  before 58 700, beside 51 300, behind 61 700
+        // Beside the fill the table kernels are some 20 000 short blocks of dependent loads among the fill's 512 000 blocks of
+        // stores and the head reaches the host long before the fill ends; on dense frames they take the fill's wave slots for
+        // 0.4 ms (fill 1.03 -> 1.30 ms) and go behind it instead, where they meet the next batch's background kernel.
+        int tmode = ctx->table_mode >= 0 ? ctx->table_mode : (ctx->dense_rows ? 2 : 1);      // (density: by the previous batch)
+        if (tmode == 1 && !(ctx->own_stream && ctx->cur == ctx->stream && ctx->side && ctx->ev_a && labels)) tmode = 0;
+        ctx->ms[6] = 0;
+        if (tmode == 0) {                                    // before the fill: the head travels to the host while the map is written
+            launch_chain_b(ctx->cur, chain_runs, chain_cap, chain_bcap);
+            { int r_ = fetch_head(ctx); if (r_) return r_; }
+            HIPCHK(hipEventRecord(ctx->ev[8], ctx->cur));
+        }
+        TIMED_RECORD(3);                                     // the labelling group ends here, the label fill begins
+        if (tmode == 1) {
+            // beside the fill, on the side stream: about 20 000 short-lived blocks of dependent loads next to the fill's 512 000
+            // blocks of stores; the head is on the host long before the fill ends, as in mode 0
+            HIPCHK(hipEventRecord(ctx->ev_a, ctx->cur));
+            HIPCHK(hipStreamWaitEvent(ctx->side, ctx->ev_a, 0));
+            if (ctx->timing) HIPCHK(hipEventRecord(ctx->ev[9], ctx->side));
+            launch_chain_b(ctx->side, chain_runs, chain_cap, chain_bcap);
+            if (ctx->timing) HIPCHK(hipEventRecord(ctx->ev[10], ctx->side));
+            { int r_ = fetch_head(ctx, ctx->side); if (r_) return r_; }
+            HIPCHK(hipEventRecord(ctx->ev[8], ctx->side));
+        }
         // (running the label fill on a second stream next to the crop / property kernels was measured: the fill takes 2.0 ms
         // instead of 0.93 ms when it shares the CUs, a net loss)
         if (labels) { int r_ = launch_fill(spec, nfg); if (r_) return r_; }
@@ -855,7 +903,14 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
         // The streaming kernels of this batch are queued.  What follows (crops, properties, hulls) waits on memory latency and
         // fills neither the vector units nor the memory system: the next batch's background kernel may run beside it.
         if (ctx->turn && ctx->early_release && !turn_released) { ctx->turn->release(); turn_released = true; }
-        HIPCHK(hipEventSynchronize(ctx->ev[3]));
+        if (tmode == 2) {                                    // behind the fill, beside the next batch's background kernel (measured:
+            launch_chain_b(ctx->cur, chain_runs, chain_cap, chain_bcap);   // the tail then outlasts that kernel and meets the next chain)
+            { int r_ = fetch_head(ctx); if (r_) return r_; }
+            HIPCHK(hipEventRecord(ctx->ev[8], ctx->cur));
+        }
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventSynchronize(ctx->ev[8]));             // (in mode 1 the table kernels have finished: the crop kernels may follow)
+        if (tmode == 1 && ctx->timing) HIPCHK(hipEventElapsedTime(&ctx->ms[6], ctx->ev[9], ctx->ev[10]));
         if (!spec) break;
         const HeadHost h0 = head_host(ctx, n);
         if (h0.totals[6] != 0) {

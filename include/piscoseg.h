@@ -191,7 +191,8 @@ int pseg_synth_frames(pseg_ctx *ctx, int n, int frame0, uint64_t seed, const int
 
 /* Duration in milliseconds of the named kernel group of the last call, measured with HIP events on the
  * context's stream: 0 = background kernel, 1 = threshold, 2 = sparse labelling chain,
- * 3 = label-map write, 4 = masks + crops + sums, 5 = whole call. */
+ * 3 = label-map write, 4 = masks + crops + sums, 5 = whole call, 6 = the table kernels (boxes, areas, ranks, rows, size scans)
+ * when they ran on the side stream beside the label-map write (0 when they ran inside group 2 or 4). */
 float pseg_last_ms(const pseg_ctx *ctx, int which);
 
 /* What the context has adapted to over the batches it has seen (no counterpart in the reference; for tests and
