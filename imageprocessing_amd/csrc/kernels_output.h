@@ -893,6 +893,76 @@ __global__ __launch_bounds__(128) void k_convex(int n_saved, const int32_t *__re
     cnt = wave_sum_u64(cnt);
     if ((threadIdx.x & 63) == 0 && cnt) atomicAdd((unsigned long long *)&q[14], cnt);
 }
+// The same hull for SMALL windows (at most CONVEX_SMALL_H rows), one WAVE per window and no LDS: on frames of 2000 objects a
+// batch saves 100 000 windows of 25 - 45 rows, and a 128-thread block with four block barriers, linked lists in LDS and six
+// merge rounds per window is all overhead (0.38 ms per batch, the second largest kernel of the tail).  Lane l holds the two
+// profile points of row l -- index 2l (between rows l-1 and l) and 2l+1 (on row l) -- in registers.  The strict hull is what
+// is left when no point lies on or above the chord of its two surviving neighbours; every round each surviving point looks up
+// its neighbours (bit scans over the two ballots of survivors, one ds_bpermute per side for the packed values of another
+// lane) and drops out if it does -- dropping a point that lies on or above a chord of two other points of the set is always
+// right, so all lanes may decide at once, and when nobody drops the chain is convex.  Typically 5 - 15 rounds of some 40
+// instructions.  Same predicate (hull_drop: collinear points dropped) and the same bound arithmetic as k_convex, hence the
+// same vertex set and the same count.  The right chain is the left chain of the negated profile (floor x = -ceil -x).
+// A lane per window with the stack in LDS was tried first: 0.136 ms for the 5 700 windows of an ordinary batch -- a chain
+// of 250 dependent LDS round trips per lane, one wave per SIMD.
+#define CONVEX_SMALL_H 63
+__device__ __forceinline__ int hull_wave_bound(int v0, int v1, bool has0, bool has1, int lane, int h)   // ceil of the lower hull at 2 lane + 1, /2
+{
+    bool a0 = has0, a1 = has1;
+    const unsigned long long below = (1ull << lane) - 1ull, above = lane == 63 ? 0ull : ~((2ull << lane) - 1ull);
+    const int packed = (int)(((uint32_t)v0 & 0xffffu) | ((uint32_t)v1 << 16));
+    int ip = 0, vp = 0, in_ = 0, vn = 0;                    // neighbours in other lanes (profile index, value)
+    bool hp = false, hn = false;
+    for (int guard = 0; guard < 256; guard++) {
+        const unsigned long long E = __ballot(a0), O = __ballot(a1), A = E | O;
+        const unsigned long long ab = A & below, aa = A & above;
+        hp = ab != 0; hn = aa != 0;
+        const int pl = hp ? 63 - __builtin_clzll(ab) : 0, nl = hn ? __builtin_ctzll(aa) : 0;
+        const int wp = __builtin_amdgcn_ds_bpermute(pl << 2, packed), wn = __builtin_amdgcn_ds_bpermute(nl << 2, packed);
+        const bool po = (O >> pl) & 1ull;                   // the last survivor of lane pl: its odd point if that survives
+        ip = 2 * pl + (po ? 1 : 0); vp = po ? (wp >> 16) : (int)(short)(wp & 0xffff);
+        const bool ne = (E >> nl) & 1ull;                   // the first survivor of lane nl: its even point if that survives
+        in_ = 2 * nl + (ne ? 0 : 1); vn = ne ? (int)(short)(wn & 0xffff) : (wn >> 16);
+        // point 0 (index 2 lane): between the survivor below and its own odd point, or the survivor above
+        const bool d0 = a0 && hp && (a1 || hn) && hull_drop<true>(ip, vp, 2 * lane, v0, a1 ? 2 * lane + 1 : in_, a1 ? v1 : vn);
+        // point 1 (index 2 lane + 1): between its own even point, or the survivor below, and the survivor above
+        const bool d1 = a1 && (a0 || hp) && hn && hull_drop<true>(a0 ? 2 * lane : ip, a0 ? v0 : vp, 2 * lane + 1, v1, in_, vn);
+        if (!__ballot(d0 || d1)) break;
+        a0 = a0 && !d0; a1 = a1 && !d1;
+    }
+    // (the neighbours found in the last round are the final ones: nothing was dropped after they were looked up)
+    if (lane >= h) return 0;
+    const int i = 2 * lane + 1;
+    if (a1) return v1 >= 0 ? (v1 + 1) >> 1 : -((-v1) >> 1);            // a vertex: ceil(v1 / 2)
+    const int ea = a0 ? 2 * lane : ip, xa = a0 ? v0 : vp, eb = in_, xb = vn;
+    const int den = eb - ea, twoden = 2 * den;
+    const int num = xa * den + (xb - xa) * (i - ea);        // 2 * den * X on the edge; column = X / 2
+    return num >= 0 ? (num + twoden - 1) / twoden : -((-num) / twoden);
+}
+__global__ __launch_bounds__(256) void k_convex_small(int n_saved, const int32_t *__restrict__ geo, const long long *__restrict__ row_off,
+                                                      const int32_t *__restrict__ rowext, long long *sums)
+{
+    const int lane = threadIdx.x & 63, s = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= n_saved) return;
+    const int h = geo[8 * (size_t)s + 4];
+    if (h > CONVEX_SMALL_H) return;                         // k_convex serves the taller ones
+    const int32_t *re = rowext + 2 * row_off[s];
+    int first = 0, last = -1;                               // first / last column of row `lane` (last = -1: no pixel, no row)
+    if (lane < h) { const int2 fl = *(const int2 *)(re + 2 * lane); first = fl.x > 32767 ? 32767 : fl.x; last = fl.y; }
+    const int LINF = 20000;
+    const int lo = last >= 0 ? 2 * first : LINF, hi = last >= 0 ? -2 * last : LINF;      // doubled columns; the right side negated
+    int lo_prev = __shfl_up(lo, 1, 64), hi_prev = __shfl_up(hi, 1, 64);
+    if (lane == 0) { lo_prev = LINF; hi_prev = LINF; }
+    // profile values (k_convex): between two rows the outer one of both, on a row its extreme pixel moved out by half a pixel
+    const bool has0 = lane <= h, has1 = lane < h;
+    const int l0 = lo_prev < lo ? lo_prev : lo, l1 = last >= 0 ? lo - 1 : LINF;
+    const int u0 = hi_prev < hi ? hi_prev : hi, u1 = last >= 0 ? hi - 1 : LINF;
+    const int L = hull_wave_bound(l0, l1, has0, has1, lane, h);
+    const int U = -hull_wave_bound(u0, u1, has0, has1, lane, h);
+    unsigned long long cnt = (lane < h && U >= L) ? (unsigned long long)(U - L + 1) : 0ull;
+    cnt = wave_sum_u64(cnt);
+    if (lane == 0) sums[(size_t)s * PSEG_NSUMS + 14] = (long long)cnt;
+}
 __global__ void k_init_sums(long long *sums, int n_saved)
 {
     size_t g = GTID;

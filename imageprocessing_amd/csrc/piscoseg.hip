@@ -93,6 +93,7 @@ struct pseg_ctx {
     int band_fallbacks = 0;       // times the index order was given up (pseg_tuning_state)
     int scan_multi_min = 16384;   // (SCAN_MULTI_MIN of kernels_output.h) PSEG_SCAN_MULTI_MIN: saved objects of the previous batch from which the size scan takes two launches
     bool crop_classes = true;     // PSEG_CROP_CLASSES=0: one size class of k_crops_sums for every band
+    bool convex_small = true;     // PSEG_CONVEX_SMALL=0: every convex hull through k_convex (no wave-per-window kernel for small windows)
     bool timing = true;           // PSEG_TIMING=0: no timing events in the stream
     bool runs_old = false;        // PSEG_RUNS_OLD=1: two-pass run extraction (k_runs) + k_band_label instead of the fused k_runs_band
     bool exclusive = true;        // the device part of a call holds the GPU's turn (PSEG_EXCLUSIVE=0: batches interleave freely)
@@ -263,6 +264,7 @@ extern "C" int pseg_create(int device, int H, int W, int max_frames, pseg_ctx **
     if (const char *e = getenv("PSEG_RUNS_OLD")) ctx->runs_old = atoi(e) != 0;
     if (const char *e = getenv("PSEG_TIMING")) ctx->timing = atoi(e) != 0;
     if (const char *e = getenv("PSEG_CROP_CLASSES")) ctx->crop_classes = atoi(e) != 0;
+    if (const char *e = getenv("PSEG_CONVEX_SMALL")) ctx->convex_small = atoi(e) != 0;
     if (const char *e = getenv("PSEG_SCAN_MULTI_MIN")) ctx->scan_multi_min = atoi(e);
     if (!ctx->exclusive) ctx->band_order = 0;                // no turns: two band kernels may share the device (see BAND_ORDER_INDEX)
     if (const char *e = getenv("PSEG_BAND_ORDER")) {
@@ -877,7 +879,8 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
         // stores and the head reaches the host long before the fill ends; on dense frames they take the fill's wave slots for
         // 0.4 ms (fill 1.03 -> 1.30 ms) and go behind it instead, where they meet the next batch's background kernel.
         int tmode = ctx->table_mode >= 0 ? ctx->table_mode : (ctx->dense_rows ? 2 : 1);      // (density: by the previous batch)
-        if (tmode == 1 && !(ctx->own_stream && ctx->cur == ctx->stream && ctx->side && ctx->ev_a && labels)) tmode = 0;
+        if (tmode == 1 && !labels) tmode = 2;                // no label map: nothing to run beside; the turn is handed on first
+        if (tmode == 1 && !(ctx->own_stream && ctx->cur == ctx->stream && ctx->side && ctx->ev_a)) tmode = 0;
         ctx->ms[6] = 0;
         if (tmode == 0) {                                    // before the fill: the head travels to the host while the map is written
             launch_chain_b(ctx->cur, chain_runs, chain_cap, chain_bcap);
@@ -989,8 +992,14 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
         if (hmax > 2700) return fail(ctx, PSEG_ERR_CAPACITY, "saved object too tall for the convex-hull kernel (limit 2700 rows)");
         if (lds_big > 48 * 1024)
             HIPCHK(hipFuncSetAttribute((const void *)k_convex, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big));
+        // windows of up to CONVEX_SMALL_H rows: a wave per window, no LDS (PSEG_CONVEX_SMALL=0: every window through k_convex)
+        const int hlo = ctx->convex_small ? CONVEX_SMALL_H : 0;
+        if (hlo > 0)
+            hipLaunchKernelGGL(k_convex_small, dim3(nblocks((size_t)n_saved, 4)), dim3(256), 0, ctx->cur, n_saved, (const int32_t *)geo,
+                               (const long long *)ctx->bits_off.p, (const int32_t *)ctx->maskbits.p, d_sums);
+        if (hmax > hlo)
         hipLaunchKernelGGL(k_convex, dim3(n_saved), dim3(128), lds_small, ctx->cur, n_saved, (const int32_t *)geo,
-                           (const long long *)ctx->bits_off.p, (const int32_t *)ctx->maskbits.p, d_sums, 0, hsmall);
+                           (const long long *)ctx->bits_off.p, (const int32_t *)ctx->maskbits.p, d_sums, hlo, hsmall);
         if (hmax > hsmall)
             hipLaunchKernelGGL(k_convex, dim3(n_saved), dim3(128), lds_big, ctx->cur, n_saved, (const int32_t *)geo,
                                (const long long *)ctx->bits_off.p, (const int32_t *)ctx->maskbits.p, d_sums, hsmall, hmax);
