@@ -112,7 +112,9 @@ __global__ __launch_bounds__(256) void k_label_fill(SegState S, const int32_t *_
     const size_t rowpix = ((size_t)f * S.H + y) * S.W;
     i32x4_t out = {0, 0, 0, 0};
     // the row's run list (L2-resident tables) decides, not the threshold plane: a read stream next to the write stream
-    // costs the stores more than the lookups do
+    // costs the stores more than the lookups do.  (One bit per row and span left by k_runs_band -- "no foreground here", 2 MB per
+    // batch read through the scalar cache, seven spans in ten stored without a look at the run tables -- made the kernel slower:
+    // 1.205 against 1.087 ms, four alternating runs on one box, round 3.)
     const int rs = seg_rowstart(S, f, y), n = seg_rowcount(S, f, y);
     {
         for (int j0 = 0; j0 < n; j0 += 64) {

@@ -57,9 +57,11 @@ struct pseg_ctx {
     hipEvent_t ev_turn = nullptr; // recorded behind the streaming part on the shared stream; the own stream waits for it
     bool own_stream = false;
     std::string err;
-    hipEvent_t ev[11] = {};        // 0..7 time the kernel groups, 8 marks the run count / the head on its way to the host,
-                                   // 9..10 time the table kernels on the side stream
+    hipEvent_t ev[12] = {};        // 0..7 time the kernel groups, 8 marks the run count / the head on its way to the host,
+                                   // 9..10 time the table kernels on the side stream, 11 the start of a deferred label fill
     float ms[7] = {};
+    bool counted_live = false;    // in g_live_ctx[device]
+    bool side_tried = false;
     hipStream_t side = nullptr;   // the table kernels (boxes, areas, ranks, rows, size scans) run here, beside the label fill
     hipEvent_t ev_a = nullptr;    // recorded on the main stream behind the enclosure tree: the side stream waits for it
     int table_mode = -1;          // where the table kernels run: 0 = before the label fill (the order of rounds 1 and 2), 1 = beside it on
@@ -99,6 +101,11 @@ struct pseg_ctx {
     bool exclusive = true;        // the device part of a call holds the GPU's turn (PSEG_EXCLUSIVE=0: batches interleave freely)
     bool shared_stream = false;   // PSEG_SHARED_STREAM=1: the streaming parts of all contexts go through one stream per device (GpuTurn)
     bool early_release = true;    // hand the turn on behind the label fill instead of behind the last kernel (PSEG_EARLY_RELEASE=0)
+    int fill_refresh = 2;         // PSEG_FILL_REFRESH=0: a deferred label fill reads its tables as the caches hold them (k_refresh_tables);
+                                  // 1: refreshed in front of the fill; 2: beside its start when the fill is on the streaming queue
+    bool stream_queue = true;     // PSEG_STREAM_QUEUE=0: the streaming kernels of a call that plans to defer its fill stay on the context's stream
+    hipEvent_t ev_b = nullptr;    // hand-overs between the context's stream and the device's streaming queue
+    bool defer_fill = true;       // PSEG_DEFER_FILL=0: a call's label fill never waits for the next call's background kernel (DevSched)
     struct GpuTurn *turn = nullptr;
     int bg_chunks = 1;            // time chunks of the streaming background kernel (PSEG_BG_CHUNKS)
     int bg_resident = 0;          // blocks of the streaming background kernel the device holds at once (0: no tail split)
@@ -109,6 +116,7 @@ struct pseg_ctx {
     bool no_bands = false;        // PSEG_NO_BANDS=1: label with the global union-find only (the path of very dense frames)
     int fill_rows = -1;           // PSEG_FILL_ROWS: 1 = label fill with one wave per row (k_label_fill_rows), 0 = one wave per
                                   // 256-pixel span, -1 (default) = by the density of the previous batch
+    bool heavy_tables = false;    // the last batch kept more than 500 objects per frame
     bool dense_rows = false;      // the last batch had FILL_ROWS_MIN or more runs per row on average
     // host results
     HostBuf h_frame_row_offset, h_frame_n_contours, h_frame_valid, h_frame_mean, h_frame_std, h_area, h_saved8;
@@ -215,6 +223,19 @@ static HeadHost head_host(const pseg_ctx *ctx, int n)
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
+#define PSEG_MAX_DEVICES 64
+// (the schedule of one device: see "one batch on the GPU at a time" below)
+struct DevSched {
+    std::mutex m;
+    std::condition_variable cv;
+    unsigned long long next = 0, serving = 0;                // tickets of phase 1
+    unsigned long long p1_done = 0;                          // phase-1 sections finished so far
+    bool busy = false;                                       // a section is being queued
+    int fills_pending = 0;                                   // calls between the end of their phase 1 and their fill
+    int in_flight = 0;                                       // calls that hold a GpuTurn object
+};
+static DevSched g_sched[PSEG_MAX_DEVICES];
+static int g_live_ctx[PSEG_MAX_DEVICES];                     // contexts alive per device (under g_sched[d].m)
 static inline unsigned nblocks(size_t n, unsigned bs = 256) { return (unsigned)((n + bs - 1) / bs); }
 static hipError_t rp_static_lookup(int device);              // device address of the no-alloc entry point's scratch array
 static void async_stop(pseg_ctx *ctx);                       // ends the context's worker thread (pseg_submit / pseg_wait)
@@ -244,10 +265,7 @@ extern "C" int pseg_create(int device, int H, int W, int max_frames, pseg_ctx **
     (void)rp_static_lookup(device);
     if (hipHostMalloc(&ctx->pin_rp.p, 256, hipHostMallocDefault) == hipSuccess) ctx->pin_rp.bytes = 256; else ctx->pin_rp.p = nullptr;
     {
-        // (normal priority: with a high-priority side stream a call hung in hipEventSynchronize as soon as a handful of
-        // contexts -- two streams each on the process's four hardware queues -- were alive; the same sequence at normal
-        // priority runs, profiles/tools/r3_hang_probe.sh)
-        if (hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) != hipSuccess) ctx->side = nullptr;
+        // (the side stream itself is created when a call first wants it: a process has four hardware queues)
         if (hipEventCreateWithFlags(&ctx->ev_a, hipEventDisableTiming) != hipSuccess) ctx->ev_a = nullptr;
         if (const char *e = getenv("PSEG_TABLE_MODE")) ctx->table_mode = atoi(e) >= 0 && atoi(e) <= 2 ? atoi(e) : -1;
     }
@@ -260,6 +278,10 @@ extern "C" int pseg_create(int device, int H, int W, int max_frames, pseg_ctx **
     }
     if (const char *e = getenv("PSEG_EXCLUSIVE")) ctx->exclusive = atoi(e) != 0;
     if (const char *e = getenv("PSEG_EARLY_RELEASE")) ctx->early_release = atoi(e) != 0;
+    if (const char *e = getenv("PSEG_DEFER_FILL")) ctx->defer_fill = atoi(e) != 0;
+    if (const char *e = getenv("PSEG_STREAM_QUEUE")) ctx->stream_queue = atoi(e) != 0;
+    if (hipEventCreateWithFlags(&ctx->ev_b, hipEventDisableTiming) != hipSuccess) ctx->ev_b = nullptr;
+    if (const char *e = getenv("PSEG_FILL_REFRESH")) ctx->fill_refresh = atoi(e);
     if (const char *e = getenv("PSEG_SHARED_STREAM")) ctx->shared_stream = atoi(e) != 0;
     if (const char *e = getenv("PSEG_RUNS_OLD")) ctx->runs_old = atoi(e) != 0;
     if (const char *e = getenv("PSEG_TIMING")) ctx->timing = atoi(e) != 0;
@@ -275,6 +297,7 @@ extern "C" int pseg_create(int device, int H, int W, int max_frames, pseg_ctx **
     if (const char *e = getenv("PSEG_NO_BANDS")) ctx->no_bands = atoi(e) != 0;
     if (const char *e = getenv("PSEG_FILL_ROWS")) ctx->fill_rows = atoi(e);
     for (auto &e : ctx->ev) if (hipEventCreate(&e) != hipSuccess) { pseg_destroy(ctx); return PSEG_ERR_HIP; }   // frees what exists so far
+    if (device < PSEG_MAX_DEVICES) { std::lock_guard<std::mutex> lk(g_sched[device].m); g_live_ctx[device]++; ctx->counted_live = true; }
     *out = ctx;
     return PSEG_OK;
 }
@@ -283,6 +306,7 @@ extern "C" int pseg_destroy(pseg_ctx *ctx)
 {
     if (!ctx) return PSEG_ERR_ARG;
     async_stop(ctx);
+    if (ctx->counted_live) { std::lock_guard<std::mutex> lk(g_sched[ctx->device].m); g_live_ctx[ctx->device]--; }
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
 #ifdef BAND_PROF
@@ -309,6 +333,7 @@ extern "C" int pseg_destroy(pseg_ctx *ctx)
     for (auto &e : ctx->ev) if (e) hipEventDestroy(e);
     if (ctx->ev_turn) hipEventDestroy(ctx->ev_turn);
     if (ctx->ev_a) hipEventDestroy(ctx->ev_a);
+    if (ctx->ev_b) hipEventDestroy(ctx->ev_b);
     if (ctx->side) hipStreamDestroy(ctx->side);
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -361,51 +386,79 @@ static int check_batch(pseg_ctx *ctx, int n)
 // batch's background kernel runs beside them at a small loss (0.92 ms for both against 0.65 + 0.38 ms one after the other).
 // Other pairings were traced and dropped: the crop chain beside the next batch's labelling kernels (both stretch: 0.64 ms
 // against 0.40 + 0.38 ms, and the background kernel alone again) comes out level.
-#define PSEG_MAX_DEVICES 64
-// first come, first served: with a plain mutex a context that has just finished can overtake one that has been waiting, and a
-// caller that collects its results in submission order (pseg_submit / pseg_wait) then sits on the overtaken one while the
-// others have nothing queued -- the pipeline runs dry (80 us of idle GPU per batch in the kernel trace)
-struct TurnLock {
-    std::mutex m;
-    std::condition_variable cv;
-    unsigned long long next = 0, serving = 0;
-    void lock()
-    {
-        std::unique_lock<std::mutex> lk(m);
-        const unsigned long long my = next++;
-        cv.wait(lk, [&] { return serving == my; });
-    }
-    void unlock()
-    {
-        { std::lock_guard<std::mutex> lk(m); serving++; }
-        cv.notify_all();
-    }
-};
-static TurnLock g_turn_mu[PSEG_MAX_DEVICES];
-static hipEvent_t g_turn_ev[PSEG_MAX_DEVICES];              // recorded behind the last streaming kernel of the previous holder
+// Schedule of one device.  The STREAMING kernels of all contexts (background kernel, label fill) run one at a time, in the order
+// in which the host queued them: each waits for the event recorded behind the one queued before it (g_turn_ev).  A call queues
+// them in two sections:
+//   phase 1: background kernel, then -- not part of the streaming order -- the labelling chain and the table kernels;
+//   phase 2: the label fill.
+// Phase 1 is first come, first served (with a plain mutex a context that has just finished could overtake one that has been
+// waiting, and a caller that collects results in submission order then sits on the overtaken one while the others have nothing
+// queued).  When another call is on its way (it waits for phase 1 already, or three calls are in flight on the device), a
+// call DEFERS its label fill until that call has queued its phase 1, so that the device sees
+//   bg(t), fill(t-1) | chain(t), bg(t+1), fill(t) | chain(t+1), ...
+// and the latency-bound labelling chain of a batch (0.16 ms during which the memory system idled) runs beside the previous
+// batch's label fill instead of alone.  No more than two fills are ever outstanding, a deferred fill is queued at the latest
+// when the streaming kernels queued so far have drained and nobody has come (a poll of g_turn_ev), and the band kernels of
+// consecutive calls are ordered among themselves by an event of their own (g_band_ev: the index-ordered look-back of
+// k_runs_band wants to be the only one of its kind on the device).
+static hipEvent_t g_turn_ev[PSEG_MAX_DEVICES];              // recorded behind the streaming kernel that was queued last
 static bool g_turn_ev_set[PSEG_MAX_DEVICES];
 static hipStream_t g_turn_last[PSEG_MAX_DEVICES];            // the stream that event was recorded on
+static hipEvent_t g_band_ev[PSEG_MAX_DEVICES];              // recorded behind the band kernel that was queued last
+static bool g_band_ev_set[PSEG_MAX_DEVICES];
+static hipStream_t g_band_last[PSEG_MAX_DEVICES];
+static hipStream_t g_sq[PSEG_MAX_DEVICES];                   // the device's streaming queue (see GpuTurn::sq)
+static bool g_sq_tried[PSEG_MAX_DEVICES];
 static hipStream_t g_main_stream[PSEG_MAX_DEVICES];          // the device's shared streaming stream
 static bool g_main_tried[PSEG_MAX_DEVICES];
 static hipStream_t g_tail_stream[PSEG_MAX_DEVICES][2];       // where the tails of consecutive calls go, alternating
 static unsigned g_tail_next[PSEG_MAX_DEVICES];
-// The streaming parts of consecutive batches (background kernel ... label fill) are queued on ONE stream per device, in
-// turn order: the next batch's background kernel follows the label fill in the same hardware queue with no cross-queue
-// dependency in between (a wait on another queue's event cost about 70 us of idle device per batch in the kernel trace).
-// The latency-bound tail of a call (crops, properties, hulls, copies) goes to one of two tail streams of the device (taken
-// in turns), behind an event recorded at the hand-over, and runs beside the next batch's background kernel.  Three streams
-// per device whatever the number of contexts: a process has few hardware queues (GPU_MAX_HW_QUEUES, 4 by default), and
-// streams that share one run in order -- with a stream per context the tail of one batch and the background kernel of the
-// next landed in the same queue and ran one after the other.  A context on a caller's stream
-// (pseg_set_stream) keeps everything on that stream and is ordered against the others through g_turn_ev.
+// PSEG_SHARED_STREAM=1 (a layout that was measured and left off): the streaming parts of consecutive batches are queued on
+// ONE stream per device, the latency-bound tail of a call (crops, properties, hulls, copies) on one of two tail streams of the
+// device, behind an event recorded at the hand-over.  A context on a caller's stream (pseg_set_stream) keeps everything on
+// that stream and is ordered against the others through g_turn_ev.
 struct GpuTurn {
-    pseg_ctx *ctx; bool held = false;
-    explicit GpuTurn(pseg_ctx *c) : ctx(c)
+    pseg_ctx *ctx;
+    enum State { IDLE, P1, PENDING, P2 } st = IDLE;
+    bool counted = false;                                    // in g_sched[d].in_flight
+    bool ev_fresh = false;                                   // g_turn_ev was recorded behind the last streaming kernel this call queued
+    // A call that expects to defer its fill (the next call is waiting, or three are in flight) queues its two streaming kernels
+    // on the device's streaming queue instead of its own stream: consecutive streaming kernels of different calls then follow
+    // each other inside one hardware queue (a wait for another queue's event is 20 - 30 us of idle streaming path, twice per
+    // batch), and the hand-overs between that queue and the context's stream lie beside a streaming kernel.
+    hipStream_t sq = nullptr;
+    bool may_defer = false;                                  // a call that writes a label map, on a context of its own, of light frames
+    // fill_expected: the call writes a label map (only then is there a fill to defer)
+    explicit GpuTurn(pseg_ctx *c, bool fill_expected = false) : ctx(c)
     {
         if (!c || !c->exclusive || c->turn || c->device < 0 || c->device >= PSEG_MAX_DEVICES) return;
         const int d = c->device;
-        g_turn_mu[d].lock();
-        held = true; c->turn = this;
+        DevSched &s = g_sched[d];
+        int live;
+        bool company;
+        {
+            std::unique_lock<std::mutex> lk(s.m);
+            const unsigned long long my = s.next++;
+            s.in_flight++; counted = true;
+            s.cv.wait(lk, [&] { return s.serving == my && !s.busy && s.fills_pending <= 1; });
+            s.busy = true;
+            // The next call is on its way when it waits for its phase 1 already, or when three calls are in flight (measured with
+            // three contexts: the next one then arrives before the previous call's fill has drained).  Frames with many runs or
+            // many objects keep the plain order: their chain and table kernels are too heavy a neighbour for a fill
+            // (uvp5_dense: 1.65 ms against 1.08 ms).
+            may_defer = fill_expected && c->defer_fill && c->own_stream && !c->shared_stream && !c->heavy_tables && !c->dense_rows;
+            company = s.next - s.serving > 1 || s.in_flight >= 3;
+            live = g_live_ctx[d];
+        }
+        st = P1; c->turn = this;
+        // (more than three contexts: the streaming queue would share one of the process's four hardware queues with a context)
+        if (may_defer && company && c->stream_queue && live <= 3 && c->ev_b && c->ev_turn) {
+            if (!g_sq_tried[d]) {                            // (inside a section: one thread at a time)
+                g_sq_tried[d] = true;
+                if (hipStreamCreateWithFlags(&g_sq[d], hipStreamNonBlocking) != hipSuccess) g_sq[d] = nullptr;
+            }
+            sq = g_sq[d];
+        }
         if (c->own_stream && c->ev_turn && c->shared_stream) {
             if (!g_main_tried[d]) {
                 g_main_tried[d] = true;
@@ -414,26 +467,129 @@ struct GpuTurn {
             }
             if (g_main_stream[d]) c->cur = g_main_stream[d];
         }
-        if (g_turn_ev_set[d] && g_turn_last[d] != c->cur) (void)hipStreamWaitEvent(c->cur, g_turn_ev[d], 0);
+        wait_streaming();
     }
-    void release()                                           // call after the last kernel of the streaming part is queued
+    bool held() const { return st == P1 || st == P2; }
+    // the stream waits for the streaming kernel that was queued last on the device (only inside a section)
+    hipStream_t target() const { return sq ? sq : ctx->cur; }  // where this call's streaming kernels go
+    void wait_streaming()
     {
-        if (!held) return;
         const int d = ctx->device;
+        if (g_turn_ev_set[d] && g_turn_last[d] != target()) (void)hipStreamWaitEvent(target(), g_turn_ev[d], 0);
+    }
+    // the stream for a streaming kernel; with_ctx: the kernel reads what the context's stream has queued so far
+    hipStream_t stream_begin(bool with_ctx)
+    {
+        if (!sq || !held()) return ctx->cur;
+        if (with_ctx) { (void)hipEventRecord(ctx->ev_b, ctx->cur); (void)hipStreamWaitEvent(sq, ctx->ev_b, 0); }
+        return sq;
+    }
+    // the kernel is queued: the context's stream goes on behind it
+    // (call streamed() first: the event it records behind the kernel serves this wait too -- every event between two kernels
+    // of a queue is 6 us of idle queue)
+    void stream_end()
+    {
+        if (!sq || !held()) return;
+        const int d = ctx->device;
+        if (ev_fresh && g_turn_ev_set[d] && g_turn_last[d] == sq) { (void)hipStreamWaitEvent(ctx->cur, g_turn_ev[d], 0); return; }
+        (void)hipEventRecord(ctx->ev_turn, sq);
+        (void)hipStreamWaitEvent(ctx->cur, ctx->ev_turn, 0);
+    }
+    // the context's stream waits for the streaming kernel queued last on the device (for work that should run beside the next one)
+    void ctx_waits_streaming()
+    {
+        const int d = ctx->device;
+        if (held() && g_turn_ev_set[d] && g_turn_last[d] != ctx->cur) (void)hipStreamWaitEvent(ctx->cur, g_turn_ev[d], 0);
+    }
+    // a streaming kernel of this call has just been queued: the next one, whoever queues it, follows it
+    void streamed()
+    {
+        if (!held()) return;
+        const int d = ctx->device;
+        std::lock_guard<std::mutex> lk(g_sched[d].m);        // (the deferred fill of another call may be polling the event)
         if (!g_turn_ev_set[d]) g_turn_ev_set[d] = hipEventCreateWithFlags(&g_turn_ev[d], hipEventDisableTiming) == hipSuccess;
-        if (g_turn_ev_set[d]) { (void)hipEventRecord(g_turn_ev[d], ctx->cur); g_turn_last[d] = ctx->cur; }
-        else (void)hipStreamSynchronize(ctx->cur);           // no event: hand over on the host
-        if (ctx->cur != ctx->stream) {                       // the rest of the call runs on a tail stream, behind what is queued
+        if (g_turn_ev_set[d]) { (void)hipEventRecord(g_turn_ev[d], target()); g_turn_last[d] = target(); ev_fresh = true; }
+    }
+    void unstreamed() { ev_fresh = false; }                  // another streaming kernel of this call follows
+    // the band kernels of consecutive calls, one at a time
+    void band_begin()
+    {
+        const int d = ctx->device;
+        if (held() && g_band_ev_set[d] && g_band_last[d] != ctx->cur) (void)hipStreamWaitEvent(ctx->cur, g_band_ev[d], 0);
+    }
+    void band_end()
+    {
+        if (!held()) return;
+        const int d = ctx->device;
+        if (!g_band_ev_set[d]) g_band_ev_set[d] = hipEventCreateWithFlags(&g_band_ev[d], hipEventDisableTiming) == hipSuccess;
+        if (g_band_ev_set[d]) { (void)hipEventRecord(g_band_ev[d], ctx->cur); g_band_last[d] = ctx->cur; }
+    }
+    // should this call's label fill wait for the next call's phase 1?
+    bool want_defer()
+    {
+        if (st != P1 || !may_defer || ctx->cur != ctx->stream || !ev_fresh) return false;
+        DevSched &s = g_sched[ctx->device];
+        std::lock_guard<std::mutex> lk(s.m);
+        return s.next - s.serving > 1 || s.in_flight >= 3;
+    }
+    // ends phase 1 and returns inside phase 2, with the stream waiting for the streaming kernel queued last
+    void defer_fill()
+    {
+        const int d = ctx->device;
+        DevSched &s = g_sched[d];
+        {
+            std::unique_lock<std::mutex> lk(s.m);
+            s.busy = false; s.serving++;
+            const unsigned long long mine = ++s.p1_done;
+            s.fills_pending++;
+            st = PENDING;
+            s.cv.notify_all();
+            for (;;) {
+                if (!s.busy) {
+                    if (s.p1_done > mine) break;             // the next call has queued its background kernel
+                    // nobody on the way and nothing streaming left on the device: waiting longer would leave it idle
+                    if (s.next == s.serving && (!g_turn_ev_set[d] || hipEventQuery(g_turn_ev[d]) != hipErrorNotReady)) break;
+                }
+                s.cv.wait_for(lk, std::chrono::microseconds(40));
+            }
+            s.busy = true;
+            st = P2;
+        }
+        wait_streaming();
+        ev_fresh = false;
+    }
+    void release()                                           // call after the last streaming kernel of the section is queued
+    {
+        if (st == IDLE) return;
+        const int d = ctx->device;
+        DevSched &s = g_sched[d];
+        if (held() && !ev_fresh) {
+            streamed();
+            if (!ev_fresh) (void)hipStreamSynchronize(target());   // no event: hand over on the host
+        }
+        if (held() && ctx->cur != ctx->stream) {             // the rest of the call runs on a tail stream, behind what is queued
             hipStream_t t = g_tail_stream[d][g_tail_next[d]++ & 1];
             if (!t) t = ctx->stream;
             (void)hipEventRecord(ctx->ev_turn, ctx->cur);
             (void)hipStreamWaitEvent(t, ctx->ev_turn, 0);
             ctx->cur = t;
         }
-        held = false; ctx->turn = nullptr;
-        g_turn_mu[d].unlock();
+        {
+            std::lock_guard<std::mutex> lk(s.m);
+            if (st == P1) { s.busy = false; s.serving++; s.p1_done++; }
+            else if (st == P2) { s.busy = false; s.fills_pending--; }
+            else if (st == PENDING) s.fills_pending--;
+            st = IDLE;
+        }
+        ctx->turn = nullptr;
+        s.cv.notify_all();
     }
-    ~GpuTurn() { release(); if (ctx) ctx->cur = ctx->stream; }
+    ~GpuTurn()
+    {
+        release();
+        if (counted) { std::lock_guard<std::mutex> lk(g_sched[ctx->device].m); g_sched[ctx->device].in_flight--; }
+        if (ctx) ctx->cur = ctx->stream;
+    }
 };
 
 // background kernel launch (+ reduction of the raw sums; masked sums too when fused).
@@ -516,10 +672,11 @@ static int run_bg(pseg_ctx *ctx, const uint8_t *frames, int n_avail, int n_emit,
             ctx->bounds_tailk = tailk;
         }
     }
-    TIMED_RECORD(0);
+    const hipStream_t bst = ctx->turn ? ctx->turn->stream_begin(false) : ctx->cur;   // (the device's streaming queue, or the context's stream)
+    if (ctx->timing) HIPCHK(hipEventRecord(ctx->ev[0], bst));
     if (stream) {
         const dim3 grid(nfull + (nblk - nfull) * tailk, chunks);
-#define BG_LAUNCH(NW_, PAD_) hipLaunchKernelGGL((k_bg_stream<NW_, PAD_>), grid, dim3(256), 0, ctx->cur, frames, P, cleaned, mask, thr,       \
+#define BG_LAUNCH(NW_, PAD_) hipLaunchKernelGGL((k_bg_stream<NW_, PAD_>), grid, dim3(256), 0, bst, frames, P, cleaned, mask, thr,       \
                                                 (uint8_t *)ctx->bits.p, (uint4 *)ctx->partials.p, (const int *)ctx->bounds.p,                \
                                                 (uint8_t *)ctx->trash.p, (uint32_t *)ctx->maskpart.p, (int)nfull, tailk)
         const bool pad = P % 2048 != 0;
@@ -535,10 +692,14 @@ static int run_bg(pseg_ctx *ctx, const uint8_t *frames, int n_avail, int n_emit,
         for (int c = 0; c < nbatch; c++) {                   // the re-reading kernel takes one batch per launch
             const size_t f0 = (size_t)c * (batch_len ? batch_len : 0);
             const int nc = batch_len ? ((c + 1) * batch_len < n_avail ? batch_len : last_len) : n;
-            hipLaunchKernelGGL(k_bg_generic, dim3(nblk, nc), dim3(256), 0, ctx->cur, frames + f0 * P, batch_len ? nc : n_kernel, NW, P,
+            hipLaunchKernelGGL(k_bg_generic, dim3(nblk, nc), dim3(256), 0, bst, frames + f0 * P, batch_len ? nc : n_kernel, NW, P,
                                cleaned + f0 * P, mask, thr, (uint8_t *)ctx->bits.p + f0 * (P / 8), (uint32_t *)ctx->partials.p + f0 * npart * 4);
         }
     HIPCHK(hipGetLastError());
+    // the next streaming kernel on the device follows this one (on the streaming queue: at once; on the context's stream the
+    // event is recorded behind the reduction, where the group's timing event lies anyway)
+    const bool on_sq = bst != ctx->cur;
+    if (ctx->turn && on_sq) { ctx->turn->streamed(); ctx->turn->stream_end(); }
     hipLaunchKernelGGL(k_reduce_partials, dim3(n), dim3(1024), 0, ctx->cur, (const uint32_t *)ctx->partials.p, (int)npart,
                        (unsigned long long)P, (unsigned long long *)ctx->fsums.p, (uint8_t *)ctx->valid_dev.p, 1, 0, 4,
                        (unsigned long long *)ctx->maskcnt.p, (uint32_t *)ctx->framebase.p + n + 1,
@@ -549,6 +710,7 @@ static int run_bg(pseg_ctx *ctx, const uint8_t *frames, int n_avail, int n_emit,
     // one event ends the background group (the reduction of the raw sums belongs to it) and starts the labelling group: every
     // event between two kernels of a stream showed as 6.5 us of idle device in the kernel trace
     TIMED_RECORD(1);
+    if (ctx->turn && !on_sq) ctx->turn->streamed();
     return 0;
 }
 
@@ -676,6 +838,20 @@ __global__ __launch_bounds__(256) void k_pack_out(const int32_t *__restrict__ ro
     if (i <= n_saved) o_crop_off[i] = crop_off[i];
 }
 
+// What the label fill reads (row table, runs, their labels: 14 MB for 200 frames) written once more in place.  A fill
+// that was deferred behind the next call's background kernel finds those tables evicted from the caches -- 2.9 GB went through
+// them since the chain wrote them -- and its waves, which live for a few microseconds, then wait for reads from memory under
+// its own store stream: 1.53 ms instead of 1.0 ms (profiles/r03/21_deferred_fill.txt).  Reading the tables ahead of the fill did
+// not help (1.43 ms), writing them does: lines that were just stored are served on-die, as they are when the fill follows
+// its own chain.
+__global__ __launch_bounds__(256) void k_refresh_tables(uint4 *a, size_t na, uint4 *b, size_t nb, uint4 *c, size_t nc)
+{
+    const size_t g = GTID, step = (size_t)gridDim.x * 256;
+    for (size_t i = g; i < na; i += step) { uint4 v = a[i]; asm volatile("" : "+v"(v.x)); a[i] = v; }
+    for (size_t i = g; i < nb; i += step) { uint4 v = b[i]; asm volatile("" : "+v"(v.x)); b[i] = v; }
+    for (size_t i = g; i < nc; i += step) { uint4 v = c[i]; asm volatile("" : "+v"(v.x)); c[i] = v; }
+}
+
 // everything after the threshold plane exists.  valid flags are in ctx->valid_dev.
 static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw, const uint8_t *mask, int n,
                       double min_seg, double min_save, int32_t *labels, pseg_table *out)
@@ -738,11 +914,12 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
         sz = (unsigned long long *)(geo + 8 * rcap);
         return 0;
     };
-    bool turn_released = false;
+    bool turn_released = false, fill_deferred = false, fill_ev11 = false;
     auto launch_fused = [&](uint32_t capv) {
         // (a batch that is repeated after its turn was handed on may meet another context's band kernel on the device: tickets)
         const int band_order = (turn_released && ctx->band_order == 1) ? 0 : ctx->band_order;
         const dim3 g(nbpf * n), b(256);
+        if (ctx->turn) ctx->turn->band_begin();              // (behind the band kernel of the call before this one)
 #define BAND_LAUNCH(WPL_, CAP_) hipLaunchKernelGGL((k_runs_band<WPL_, CAP_>), g, b, 0, ctx->cur, S, runs_wpl, capv, scan, bandmax_d, band_order)
         if (runs_wpl > 10) {
             if (ctx->band_cap > BAND_CAP_MID) BAND_LAUNCH(16, BAND_CAP_DENSE);
@@ -754,6 +931,7 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
             else BAND_LAUNCH(10, BAND_CAP);
         }
 #undef BAND_LAUNCH
+        if (ctx->turn) ctx->turn->band_end();
         if (H > BAND_H) hipLaunchKernelGGL(k_unions_rows, dim3((H - 1) / BAND_H, n), dim3(64), 0, ctx->cur, S, BAND_H, capv, (uint32_t)ctx->band_cap);
     };
     // The chain behind the band labelling comes in two parts.  Part A is what the label map needs: the enclosure tree and the
@@ -784,7 +962,7 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
                            (const uint32_t *)(savedbase + n), (long long *)ctx->crop_off.p, (long long *)ctx->bits_off.p,
                            (long long *)ctx->band_off.p, totals, (const unsigned long long *)ctx->scan_part.p);
     };
-    auto launch_fill = [&](bool spec_, int nfg_) -> int {
+    auto launch_fill = [&](hipStream_t fst, bool spec_, int nfg_) -> int {
         // one wave per row where rows hold many runs (FILL_ROWS_MIN per row on average: 1.0 ms against 1.7 ms at 19 runs per
         // row), one wave per 256-pixel span otherwise (0.86 ms against 0.96 ms at 3 runs per row); the speculative chain
         // does not know this batch's count yet and goes by the previous batch
@@ -792,9 +970,9 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
                                                  : (spec_ ? ctx->dense_rows : (size_t)nfg_ >= (size_t)n * H * FILL_ROWS_MIN);
         const uint32_t c0 = spec_ ? (uint32_t)ctx->runcap : 0xffffffffu, c1 = spec_ ? (uint32_t)ctx->band_cap : 0xffffffffu;
         if (by_rows)
-            hipLaunchKernelGGL(k_label_fill_rows, dim3(1, (H + 3) / 4, n), dim3(256), 0, ctx->cur, S, (const int32_t *)ctx->runlabel.p, labels, c0, c1);
+            hipLaunchKernelGGL(k_label_fill_rows, dim3(1, (H + 3) / 4, n), dim3(256), 0, fst, S, (const int32_t *)ctx->runlabel.p, labels, c0, c1);
         else
-            hipLaunchKernelGGL(k_label_fill, dim3((W + 1023) / 1024, H, n), dim3(256), 0, ctx->cur, S, (const int32_t *)ctx->runlabel.p, labels, c0, c1);
+            hipLaunchKernelGGL(k_label_fill, dim3((W + 1023) / 1024, H, n), dim3(256), 0, fst, S, (const int32_t *)ctx->runlabel.p, labels, c0, c1);
         HIPCHK(hipGetLastError());
         return 0;
     };
@@ -878,8 +1056,24 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
         // Beside the fill the table kernels are some 20 000 short blocks of dependent loads among the fill's 512 000 blocks of
         // stores and the head reaches the host long before the fill ends; on dense frames they take the fill's wave slots for
         // 0.4 ms (fill 1.03 -> 1.30 ms) and go behind it instead, where they meet the next batch's background kernel.
+        // A call that knows the next one is on its way lets that call's background kernel go first (DevSched): the labelling
+        // chain above then runs beside the PREVIOUS call's label fill, and this fill beside the next call's chain.
+        const bool defer = labels && ctx->turn && ctx->turn->want_defer();
         int tmode = ctx->table_mode >= 0 ? ctx->table_mode : (ctx->dense_rows ? 2 : 1);      // (density: by the previous batch)
+        // (a deferred fill: the table kernels follow the chain on the main stream -- a side stream shares its hardware queue, of
+        // which a process has four, with another context's main stream, whose label fill then waited behind these kernels)
+        // (frames with hundreds of objects: 0.4 ms of table kernels, which the previous call's fill would have beside it together
+        // with this call's chain -- 1.67 ms for that fill against 1.27 ms; they go behind this call's own fill instead)
+        if (defer && tmode == 1) tmode = ctx->heavy_tables ? 2 : 0;
+        if (tmode == 1 && ctx->turn && ctx->turn->sq) tmode = 0;   // (a call on the streaming queue that does not defer after all)
         if (tmode == 1 && !labels) tmode = 2;                // no label map: nothing to run beside; the turn is handed on first
+        if (tmode == 1 && ctx->own_stream && ctx->cur == ctx->stream && !ctx->side && !ctx->side_tried) {
+            ctx->side_tried = true;
+            // (normal priority: with a high-priority side stream a call hung in hipEventSynchronize as soon as a handful of
+            // contexts -- two streams each on the process's four hardware queues -- were alive; the same sequence at normal
+            // priority runs, profiles/tools/r3_hang_probe.sh)
+            if (hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) != hipSuccess) ctx->side = nullptr;
+        }
         if (tmode == 1 && !(ctx->own_stream && ctx->cur == ctx->stream && ctx->side && ctx->ev_a)) tmode = 0;
         ctx->ms[6] = 0;
         if (tmode == 0) {                                    // before the fill: the head travels to the host while the map is written
@@ -901,8 +1095,30 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
         }
         // (running the label fill on a second stream next to the crop / property kernels was measured: the fill takes 2.0 ms
         // instead of 0.93 ms when it shares the CUs, a net loss)
-        if (labels) { int r_ = launch_fill(spec, nfg); if (r_) return r_; }
-        TIMED_RECORD(4);
+        fill_deferred = false; fill_ev11 = false;
+        if (defer) { ctx->turn->defer_fill(); fill_deferred = true; }
+        if (labels) {
+            // (the fill goes to the device's streaming queue when the call's background kernel went there; that queue then
+            // waits for what the context's stream has queued so far -- the chain)
+            hipStream_t fst = ctx->cur;
+            if (ctx->turn) { ctx->turn->unstreamed(); fst = ctx->turn->stream_begin(true); }
+            if (fill_deferred && ctx->fill_refresh) {        // (whole 16-byte pieces: the tables' capacities are padded)
+                // On the streaming queue the fill does not wait for it: the refresh runs on the context's stream from the moment
+                // the next call's background kernel ends, beside the fill's first 40 us (it stores the values that are there: a
+                // wave of the fill reads the same bytes before and after).
+                const bool beside = fst != ctx->cur && ctx->fill_refresh == 2;
+                if (beside) ctx->turn->ctx_waits_streaming();
+                const size_t cap_ = spec ? ctx->runcap : (size_t)nfg;
+                hipLaunchKernelGGL(k_refresh_tables, dim3(4096), dim3(256), 0, beside ? ctx->cur : fst, (uint4 *)S.rowoff, (size_t)n * (H + 1) / 4,
+                                   (uint4 *)S.run_x, cap_ / 4, (uint4 *)ctx->runlabel.p, cap_ / 4);
+            }
+            if ((fill_deferred || fst != ctx->cur) && ctx->timing) { HIPCHK(hipEventRecord(ctx->ev[11], fst)); fill_ev11 = true; }
+            int r_ = launch_fill(fst, spec, nfg);
+            if (r_) return r_;
+            if (ctx->timing) HIPCHK(hipEventRecord(ctx->ev[4], fst));
+            if (ctx->turn && fst != ctx->cur) { ctx->turn->streamed(); ctx->turn->stream_end(); }
+        } else
+            TIMED_RECORD(4);
         // The streaming kernels of this batch are queued.  What follows (crops, properties, hulls) waits on memory latency and
         // fills neither the vector units nor the memory system: the next batch's background kernel may run beside it.
         if (ctx->turn && ctx->early_release && !turn_released) { ctx->turn->release(); turn_released = true; }
@@ -936,6 +1152,7 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
     // size class of the band kernel for the next call: the large tables as soon as a band asked for them, the small ones
     // again after 8 calls that would have fitted with room to spare
     ctx->dense_rows = (size_t)nfg >= (size_t)n * H * FILL_ROWS_MIN;
+    ctx->heavy_tables = (size_t)head_host(ctx, n).rowbase[n] > (size_t)n * 500;
     {
         auto class_for = [](uint32_t b) { return b <= BAND_CAP ? BAND_CAP : (b <= BAND_CAP_MID ? BAND_CAP_MID : BAND_CAP_DENSE); };
         const int need = class_for(band_seen), roomy = class_for(band_seen + band_seen / 3);
@@ -1032,7 +1249,7 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
     const auto hp_t0 = std::chrono::steady_clock::now();
 #endif
     TIMED_ELAPSED(2, 1, 3);
-    TIMED_ELAPSED(3, 3, 4);
+    TIMED_ELAPSED(3, fill_ev11 ? 11 : 3, 4);
     TIMED_ELAPSED(4, 4, 5);
 
     int32_t *h_fro = ctx->h_frame_row_offset.as<int32_t>(n + 1);
@@ -1087,19 +1304,23 @@ extern "C" int pseg_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t 
     ENSURE(ctx->partials, (size_t)n * npart * 4 * sizeof(uint32_t));
     ENSURE(ctx->maskpart, (size_t)npart * 4 + 16);
     { int r_ = head_setup(ctx, n); if (r_) return r_; }
-    GpuTurn turn(ctx);
+    // (the two-call path never defers its fill: between its calls runs the caller's network, a streaming kernel the library does
+    // not order -- with deferred fills the stand-in bench lost 4 %)
+    GpuTurn turn(ctx, false);
     TIMED_RECORD(6);
     if (valid) HIPCHK(hipMemcpyAsync(ctx->valid_dev.p, valid, n, hipMemcpyHostToDevice, ctx->cur));
     else HIPCHK(hipMemsetAsync(ctx->valid_dev.p, 1, n, ctx->cur));
-    TIMED_RECORD(0);
+    const hipStream_t tst = ctx->turn ? ctx->turn->stream_begin(true) : ctx->cur;
+    if (ctx->timing) HIPCHK(hipEventRecord(ctx->ev[0], tst));
     {
         const dim3 grid(nblk, (n + THR_FCHUNK - 1) / THR_FCHUNK);
         if (P % 2048 == 0)
-            hipLaunchKernelGGL(k_threshold<false>, grid, dim3(256), 0, ctx->cur, cleaned, P, mask, threshold, (uint8_t *)ctx->bits.p, (uint4 *)ctx->partials.p, n, (uint32_t *)ctx->maskpart.p);
+            hipLaunchKernelGGL(k_threshold<false>, grid, dim3(256), 0, tst, cleaned, P, mask, threshold, (uint8_t *)ctx->bits.p, (uint4 *)ctx->partials.p, n, (uint32_t *)ctx->maskpart.p);
         else
-            hipLaunchKernelGGL(k_threshold<true>, grid, dim3(256), 0, ctx->cur, cleaned, P, mask, threshold, (uint8_t *)ctx->bits.p, (uint4 *)ctx->partials.p, n, (uint32_t *)ctx->maskpart.p);
+            hipLaunchKernelGGL(k_threshold<true>, grid, dim3(256), 0, tst, cleaned, P, mask, threshold, (uint8_t *)ctx->bits.p, (uint4 *)ctx->partials.p, n, (uint32_t *)ctx->maskpart.p);
     }
     HIPCHK(hipGetLastError());
+    if (ctx->turn && tst != ctx->cur) { ctx->turn->streamed(); ctx->turn->stream_end(); }
     hipLaunchKernelGGL(k_reduce_partials, dim3(n), dim3(1024), 0, ctx->cur, (const uint32_t *)ctx->partials.p, (int)npart,
                        (unsigned long long)P, (unsigned long long *)ctx->fsums.p, (uint8_t *)ctx->valid_dev.p, 0, 2, 2,
                        (unsigned long long *)ctx->maskcnt.p, (uint32_t *)ctx->framebase.p + n + 1, (const uint32_t *)ctx->maskpart.p,
@@ -1107,6 +1328,7 @@ extern "C" int pseg_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t 
     ctx->mask_counted = mask != nullptr;                     // (k_threshold left per-wave counts of the mask pixels)
     HIPCHK(hipGetLastError());
     TIMED_RECORD(1);
+    if (ctx->turn && tst == ctx->cur) ctx->turn->streamed();
     r = run_detect(ctx, cleaned, raw, mask, n, min_area_to_segment, min_area_to_save, labels, out);
     if (r) return r;
     HIPCHK(hipEventRecord(ctx->ev[7], ctx->cur));
@@ -1126,7 +1348,7 @@ static int process_impl(pseg_ctx *ctx, const uint8_t *frames, int n_avail, int n
     if (!frames || !cleaned) return fail(ctx, PSEG_ERR_ARG, "null frame pointer");
     if (n_emit < 1 || n_emit > n_avail) return fail(ctx, PSEG_ERR_ARG, "n_emit out of range");
     const int n = n_emit;
-    GpuTurn turn(ctx);
+    GpuTurn turn(ctx, labels != nullptr);
     TIMED_RECORD(6);
     r = run_bg(ctx, frames, n_avail, n_emit, n_bg_imgs, mask, threshold, cleaned, batch_len);
     if (r) return r;

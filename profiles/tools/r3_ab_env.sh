@@ -1,10 +1,13 @@
 # A/B of one environment switch on one box: r3_ab_env.sh VAR "v1 v2 ..." [workloads...]; runs the parity tests first
+# (workload = name:bench_args with _ for spaces, e.g. nolabels:--no-labels densesaved:--workload_uvp5_dense_saved)
 set -e
 cd $GRAFT_REPO_ROOT
 VAR=$1; VALS=$2; shift 2
 WL=${@:-"default: densesaved:--workload_uvp5_dense_saved"}
+if [ -z "$AB_SKIP_TESTS" ]; then
 timeout -k 10 600 python -u -m pytest tests/test_gpu_parity.py tests/test_gpu_dense.py tests/test_gpu_async.py tests/test_gpu_dropin.py -m gpu -x -q --timeout 300 --timeout-method thread > gpurun_out/ab_tests.log 2>&1 || { tail -40 gpurun_out/ab_tests.log; exit 1; }
 tail -1 gpurun_out/ab_tests.log
+fi
 for rep in 1 2; do
 for val in $VALS; do
 for v in $WL; do
