@@ -554,6 +554,10 @@ def main():
                  # had to give the index order up (a timed-out scan: the batch is repeated inside the call)
                  "band_scan_order": [s_.tuning_state()["band_order"] for s_ in segs],
                  "band_scan_fallbacks": sum(s_.tuning_state()["band_order_fallbacks"] for s_ in segs),
+                 # calls whose label fill waited for the next call's background kernel (the labelling chain then runs beside the
+                 # previous call's fill: its avg_ms in roofline_groups is the time beside that fill, not device time of its own)
+                 "fills_deferred": sum(s_.tuning_state()["fills_deferred"] for s_ in segs),
+                 "calls_on_streaming_queue": sum(s_.tuning_state()["calls_on_streaming_queue"] for s_ in segs),
                  "ranks_seen": dist.get_world_size() if dist_on else 1, "launch": launch,
                  "halo_overhead": round(halo, 4) if strong else 0.0,
                  "table_gather_messages_per_step": n_gather if dist_on else None,

@@ -60,6 +60,7 @@ struct pseg_ctx {
     hipEvent_t ev[12] = {};        // 0..7 time the kernel groups, 8 marks the run count / the head on its way to the host,
                                    // 9..10 time the table kernels on the side stream, 11 the start of a deferred label fill
     float ms[7] = {};
+    long long n_deferred = 0, n_on_queue = 0;   // calls whose label fill was deferred / whose streaming kernels went to the device's streaming queue (pseg_tuning_state 7 / 8)
     bool counted_live = false;    // in g_live_ctx[device]
     bool side_tried = false;
     hipStream_t side = nullptr;   // the table kernels (boxes, areas, ranks, rows, size scans) run here, beside the label fill
@@ -353,6 +354,8 @@ extern "C" long long pseg_tuning_state(const pseg_ctx *ctx, int which)
     case 4: return ctx->band_order;
     case 5: return ctx->band_fallbacks;
     case 6: return ctx->last_bg_stream;
+    case 7: return ctx->n_deferred;
+    case 8: return ctx->n_on_queue;
     default: return -1;
     }
 }
@@ -458,6 +461,7 @@ struct GpuTurn {
                 if (hipStreamCreateWithFlags(&g_sq[d], hipStreamNonBlocking) != hipSuccess) g_sq[d] = nullptr;
             }
             sq = g_sq[d];
+            if (sq) c->n_on_queue++;
         }
         if (c->own_stream && c->ev_turn && c->shared_stream) {
             if (!g_main_tried[d]) {
@@ -941,7 +945,8 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
     auto launch_chain_a = [&](size_t runs, uint32_t capv, uint32_t bcap) {
         const size_t nbgr = runs + (size_t)n * H;
         hipLaunchKernelGGL(k_flatten_resolve, dim3(nblocks(nbgr)), dim3(256), 0, ctx->cur, S, capv, bcap);
-        hipLaunchKernelGGL(k_rank_ext, dim3(n), dim3(1024), 0, ctx->cur, S, ftot3, (int32_t *)ctx->runlabel.p, capv, bcap);
+        // (the run labels only feed the label fill; k_rank counts the external contours again for the table)
+        if (labels) hipLaunchKernelGGL(k_rank_ext, dim3(n), dim3(1024), 0, ctx->cur, S, ftot3, (int32_t *)ctx->runlabel.p, capv, bcap);
     };
     auto launch_chain_b = [&](hipStream_t st, size_t runs, uint32_t capv, uint32_t bcap) {
         if (runs > 0) {
@@ -1096,7 +1101,7 @@ static int run_detect(pseg_ctx *ctx, const uint8_t *cleaned, const uint8_t *raw,
         // (running the label fill on a second stream next to the crop / property kernels was measured: the fill takes 2.0 ms
         // instead of 0.93 ms when it shares the CUs, a net loss)
         fill_deferred = false; fill_ev11 = false;
-        if (defer) { ctx->turn->defer_fill(); fill_deferred = true; }
+        if (defer) { ctx->turn->defer_fill(); fill_deferred = true; ctx->n_deferred++; }
         if (labels) {
             // (the fill goes to the device's streaming queue when the call's background kernel went there; that queue then
             // waits for what the context's stream has queued so far -- the chain)

@@ -205,7 +205,11 @@ float pseg_last_ms(const pseg_ctx *ctx, int which);
  * PSEG_BAND_ORDER=0 starts there, and so do contexts that take no turns, PSEG_EXCLUSIVE=0; several processes sharing one GPU
  * should set it: their band kernels can block each other in index order until the bound, about 0.1 s, ends it),
  * 5 = times that has happened, 6 = 1 when the last background correction ran the streaming kernel (windows of 8, 10, 12, 16
- * frames in batches of at least one window), 0 the kernel that re-reads the window per frame, -1 before the first call.
+ * frames in batches of at least one window), 0 the kernel that re-reads the window per frame, -1 before the first call,
+ * 7 = calls of this context whose label-map write was deferred behind the next call's background kernel (several contexts
+ * in flight on one GPU: the labelling of a batch then runs beside the previous batch's label-map write; DESIGN.md section 3;
+ * PSEG_DEFER_FILL=0 turns it off), 8 = calls whose background kernel and label-map write were queued on the device's shared
+ * streaming queue instead of the context's own stream (PSEG_STREAM_QUEUE=0 turns that off).
  * Returns -1 for a bad argument. */
 long long pseg_tuning_state(const pseg_ctx *ctx, int which);
 

@@ -17,12 +17,25 @@ def _same_table(a, b):
         assert np.array_equal(a.crops[plane], b.crops[plane]), plane
 
 
-def test_pipelined_submissions_equal_synchronous_calls():
+# the schedules of round 3 ("Schedule of one device"): with three calls in flight a call's label fill is
+# deferred behind the next call's background kernel, both on the device's streaming queue; every switch gives the same results
+@pytest.mark.parametrize("ncontexts,env,deferred", [
+    (3, {}, True),
+    (3, {"PSEG_DEFER_FILL": "0"}, False),
+    (3, {"PSEG_STREAM_QUEUE": "0"}, True),
+    (3, {"PSEG_FILL_REFRESH": "1"}, True),
+    (3, {"PSEG_FILL_REFRESH": "0"}, True),
+    (5, {}, True),                                         # more than three contexts alive: no streaming queue
+    (2, {}, None),                                         # two calls in flight: deferred only when the next call is waiting already
+])
+def test_pipelined_submissions_equal_synchronous_calls(monkeypatch, ncontexts, env, deferred):
     import torch
     from imageprocessing_amd import synth
     from imageprocessing_amd.engine import Segmenter
-    H, W, n, nbatch = 256, 320, 40, 7
-    segs = [Segmenter(H, W, max_frames=n, device=0) for _ in range(3)]
+    H, W, n, nbatch = 256, 320, 40, 11
+    for k_, v_ in env.items():
+        monkeypatch.setenv(k_, v_)
+    segs = []
     ref = Segmenter(H, W, max_frames=n, device=0)
     try:
         mask = torch.from_numpy(helpers.make_disk(H, W, 120)).cuda()
@@ -41,6 +54,10 @@ def test_pipelined_submissions_equal_synchronous_calls():
         # batch 0 against the oracle, so that "equal to the synchronous call" means "equal to the reference"
         dets = helpers.oracle_detect(helpers.oracle_bgcorrect(stacks[0].cpu().numpy()), mask.cpu().numpy())
         helpers.compare_table(want[0][3], dets, H, W, labels=want[0][4].cpu().numpy())
+        assert ref.tuning_state()["fills_deferred"] == 0    # a context alone never defers
+        ref.close()                                        # (the streaming queue is for up to three contexts alive on the device)
+        ref = None
+        segs.extend(Segmenter(H, W, max_frames=n, device=0) for _ in range(ncontexts))
         labs = [torch.empty((n, H, W), dtype=torch.int32, device="cuda") for _ in segs]
         got = [None] * nbatch
         inflight = []                                      # (batch, context index), oldest first
@@ -62,8 +79,16 @@ def test_pipelined_submissions_equal_synchronous_calls():
             assert np.array_equal(got[b][1], want[b][1]) and np.array_equal(got[b][2], want[b][2])
             _same_table(got[b][3], want[b][3])
             assert torch.equal(got[b][4], want[b][4])
+        st = [s_.tuning_state() for s_ in segs]
+        n_def = sum(t["fills_deferred"] for t in st)
+        n_q = sum(t["calls_on_streaming_queue"] for t in st)
+        if deferred is True:
+            assert n_def > 0
+            assert (n_q > 0) == (ncontexts <= 3 and env.get("PSEG_STREAM_QUEUE") != "0")
+        elif deferred is False:
+            assert n_def == 0 and n_q == 0
     finally:
-        for s in segs + [ref]:
+        for s in segs + ([ref] if ref is not None else []):
             s.close()
 
 
