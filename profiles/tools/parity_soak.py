@@ -6,7 +6,9 @@ Mode "parts": parity_soak.py parts <first seed> <number of seeds> -- stacks of 3
 last one 200 - 399): cleaned frames, label maps, statistics and merged tables identical.
 Mode "bg": parity_soak.py bg <first seed> <number of seeds> -- the fused call (background correction + detection) on random stacks
 of 12 - 90 frames (smooth fields + noise + a few flat frames that fail the std > 2 gate), random time chunks and pretended block
-slots, against oracle correct_img / detect_on_img: cleaned frames bit for bit, raw and masked mean / std, validity, full tables."""
+slots, against oracle correct_img / detect_on_img: cleaned frames bit for bit, raw and masked mean / std, validity, full tables.
+Mode "pipe": parity_soak.py pipe <first seed> <number of seeds> -- the same kind of stacks through three contexts in flight
+(round 3: deferred label fills on the device's streaming queue), every batch against the oracle."""
 import sys, time
 import numpy as np
 sys.path.insert(0, '.')
@@ -121,6 +123,74 @@ def soak_parts(first, count):
     print(f"parity soak (frame ranges with halos against whole batches): seeds {first}..{first + count - 1}: {frames} frames, {nparts} parts over 2 - 8 ranks -- all equal ({time.time() - t0:.0f} s)")
 
 
+def soak_pipe(first, count):
+    """the fused call through THREE CONTEXTS IN FLIGHT (pseg_submit / pseg_wait: deferred label fills, the streaming queue,
+    refreshed tables -- DESIGN.md section 3, "Schedule of one device") on random stacks, every batch against the oracle"""
+    t0 = time.time()
+    frames = rows = deferred = 0
+    for seed in range(first, first + count):
+        rng = np.random.default_rng(555000 + seed)
+        H, W = [(64, 128), (96, 192), (128, 256), (200, 320)][seed % 4]
+        nb = 7
+        n = int(rng.integers(14, 60))
+        yy, xx = np.mgrid[0:H, 0:W]
+        mask = helpers.make_disk(H, W, min(H, W) // 2 - 3)
+        stacks = []
+        for b in range(nb):
+            base = rng.integers(120, 230)
+            stack = np.empty((n, H, W), np.uint8)
+            for f in range(n):
+                img = base + 20 * np.sin(xx / 37.0 + f / 5.0) + 10 * np.cos(yy / 23.0) + rng.normal(0, 6, (H, W))
+                for _ in range(int(rng.integers(0, 6))):
+                    cy, cx, r = rng.integers(0, H), rng.integers(0, W), rng.integers(2, 16)
+                    img[(yy - cy) ** 2 + (xx - cx) ** 2 <= r * r] -= rng.integers(40, 120)
+                stack[f] = np.clip(img, 0, 255).astype(np.uint8)
+            for f in rng.integers(0, n, int(rng.integers(0, 3))):
+                stack[f] = rng.integers(0, 256)
+            stacks.append(stack)
+        segs = [Segmenter(H, W, max_frames=n, device=0) for _ in range(3)]
+        try:
+            dmask = torch.from_numpy(mask).cuda()
+            dev = [torch.from_numpy(st).cuda() for st in stacks]
+            labs = [torch.empty((n, H, W), dtype=torch.int32, device="cuda") for _ in segs]
+            got = [None] * nb
+            inflight = []
+            def take():
+                b0, k0 = inflight.pop(0)
+                c, ms, v, tab = segs[k0].wait(fetch_crops=True)
+                got[b0] = (c.cpu().numpy(), ms.copy(), v.copy(), tab, labs[k0].cpu().numpy())
+            for b in range(nb):
+                k = b % 3
+                if len(inflight) == 3:
+                    take()
+                segs[k].submit(dev[b], mask=dmask, labels=labs[k], min_area_to_segment=3, min_area_to_save=30)
+                inflight.append((b, k))
+            while inflight:
+                take()
+            deferred += sum(s_.tuning_state()["fills_deferred"] for s_ in segs)
+            for b in range(nb):
+                items = helpers.oracle_bgcorrect(stacks[b])
+                dets = helpers.oracle_detect(items, mask, min_area_to_segment=3, min_area_to_save=30)
+                cl, ms, valid, tab, lab = got[b]
+                for i, it in enumerate(items):
+                    np.testing.assert_allclose(ms[i], it[2], rtol=1e-9, atol=1e-9)
+                    assert valid[i] == (0 if isinstance(it[1], list) else 1)
+                    if valid[i]:
+                        assert np.array_equal(cl[i], it[1]), f"seed {seed} batch {b} frame {i}"
+                helpers.compare_table(tab, dets, H, W, labels=lab)
+                frames += n; rows += tab.n_rows
+        finally:
+            for s_ in segs:
+                s_.close()
+        if (seed - first) % 10 == 9:
+            print(f"pipe seed {seed}: {frames} frames, {rows} rows equal to the oracle, {deferred} fills deferred, {time.time() - t0:.0f} s", flush=True)
+    print(f"parity soak (three contexts in flight, deferred fills): seeds {first}..{first + count - 1}: {frames} frames, {rows} rows, "
+          f"{deferred} deferred fills -- all equal to the oracle ({time.time() - t0:.0f} s)")
+
+
+if sys.argv[1] == "pipe":
+    soak_pipe(int(sys.argv[2]), int(sys.argv[3]))
+    sys.exit(0)
 if sys.argv[1] == "parts":
     soak_parts(int(sys.argv[2]), int(sys.argv[3]))
     sys.exit(0)
