@@ -228,6 +228,10 @@ def main():
     os.dup2(2, 1)
     dist_on = world > 1 or args.force_dist
     if dist_on:
+        # frame-sharded runs pack and gather a table between a wait and the next submit: the next call arrives too late for the
+        # library's deferred label fills to pay (each adds a millisecond of latency to its call; 96 000 - 103 000 against
+        # 103 000 - 106 000 frames/s with --force-dist on one GPU, profiles/r03/21_deferred_fill.txt), so they stay off here
+        os.environ.setdefault("PSEG_DEFER_FILL", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29541")
         os.environ.setdefault("RANK", "0")
@@ -517,7 +521,12 @@ def main():
                         "achieved_GBps": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4),
                         "counter_bytes": None if tr is None else int(tr * frames_per_call / BATCH),
                         "counter_over_algorithmic": None if (tr is None or b == 0) else round(tr * frames_per_call / BATCH / b, 3)}
-    dom_name = max((g for g in groups if g != "table_beside_label_map"), key=lambda g: groups[g]["avg_ms"])
+    # the dominant kernel group: among the groups that own their time (with deferred fills the labelling chain runs beside the
+    # previous call's label fill and the crop tail beside the next background kernel: their avg_ms is time spent beside a
+    # streaming kernel, not device time of their own)
+    n_deferred = sum(s_.tuning_state()["fills_deferred"] for s_ in segs)
+    beside = {"table_beside_label_map"} | ({"sparse_labelling"} if n_deferred > 0 else set())
+    dom_name = max((g for g in groups if g not in beside), key=lambda g: groups[g]["avg_ms"])
     dom = groups[dom_name]
     path_bytes = PATH_BYTES_PER_FRAME if labels_on else 2 * P
     halo = (loaded - emitted) / max(emitted, 1)
@@ -558,6 +567,7 @@ def main():
                  # previous call's fill: its avg_ms in roofline_groups is the time beside that fill, not device time of its own)
                  "fills_deferred": sum(s_.tuning_state()["fills_deferred"] for s_ in segs),
                  "calls_on_streaming_queue": sum(s_.tuning_state()["calls_on_streaming_queue"] for s_ in segs),
+                 "deferred_fills_given_up": sum(s_.tuning_state()["deferred_fills_given_up"] for s_ in segs),
                  "ranks_seen": dist.get_world_size() if dist_on else 1, "launch": launch,
                  "halo_overhead": round(halo, 4) if strong else 0.0,
                  "table_gather_messages_per_step": n_gather if dist_on else None,

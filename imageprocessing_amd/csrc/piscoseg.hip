@@ -60,6 +60,7 @@ struct pseg_ctx {
     hipEvent_t ev[12] = {};        // 0..7 time the kernel groups, 8 marks the run count / the head on its way to the host,
                                    // 9..10 time the table kernels on the side stream, 11 the start of a deferred label fill
     float ms[7] = {};
+    long long n_gaveup = 0;       // deferred fills that were queued because nobody came (pseg_tuning_state 9)
     long long n_deferred = 0, n_on_queue = 0;   // calls whose label fill was deferred / whose streaming kernels went to the device's streaming queue (pseg_tuning_state 7 / 8)
     bool counted_live = false;    // in g_live_ctx[device]
     bool side_tried = false;
@@ -234,6 +235,16 @@ struct DevSched {
     bool busy = false;                                       // a section is being queued
     int fills_pending = 0;                                   // calls between the end of their phase 1 and their fill
     int in_flight = 0;                                       // calls that hold a GpuTurn object
+    // A deferred fill that ends by giving up (the streaming kernels drained and the next call had not come) has gained nothing
+    // and meets the crop tail of the call before it.  Callers that resubmit slowly (bench.py --gpus N packs tables between a
+    // wait and the next submit) produce mostly those.  A window of 4 deferred fills fails when 2 or more end that way; after
+    // two failed windows in a row (one alone is what the first calls of any caller look like) the device keeps the plain order for
+    // the next 64 calls and then tries one window again -- 128, 256, ... 8192 calls while the trials keep failing.
+    int window_deferred = 0, window_gaveup = 0, fail_streak = 0, hold = 0, hold_len = 64;
+    // (a sign that looked cheaper -- a call that arrives when the streaming kernels queued before it have drained found the
+    // device waiting for the host -- does not tell the two kinds of callers apart: in the plain order a call of the pipelined
+    // bench arrives beside the previous call's crop kernels, with nothing streaming queued; measured and removed)
+    unsigned long long total_gaveup = 0;
 };
 static DevSched g_sched[PSEG_MAX_DEVICES];
 static int g_live_ctx[PSEG_MAX_DEVICES];                     // contexts alive per device (under g_sched[d].m)
@@ -356,6 +367,7 @@ extern "C" long long pseg_tuning_state(const pseg_ctx *ctx, int which)
     case 6: return ctx->last_bg_stream;
     case 7: return ctx->n_deferred;
     case 8: return ctx->n_on_queue;
+    case 9: return ctx->n_gaveup;
     default: return -1;
     }
 }
@@ -450,6 +462,7 @@ struct GpuTurn {
             // many objects keep the plain order: their chain and table kernels are too heavy a neighbour for a fill
             // (uvp5_dense: 1.65 ms against 1.08 ms).
             may_defer = fill_expected && c->defer_fill && c->own_stream && !c->shared_stream && !c->heavy_tables && !c->dense_rows;
+            if (may_defer && s.hold > 0) { s.hold--; may_defer = false; }
             company = s.next - s.serving > 1 || s.in_flight >= 3;
             live = g_live_ctx[d];
         }
@@ -548,13 +561,22 @@ struct GpuTurn {
             s.fills_pending++;
             st = PENDING;
             s.cv.notify_all();
+            bool gaveup = false;
             for (;;) {
                 if (!s.busy) {
                     if (s.p1_done > mine) break;             // the next call has queued its background kernel
                     // nobody on the way and nothing streaming left on the device: waiting longer would leave it idle
-                    if (s.next == s.serving && (!g_turn_ev_set[d] || hipEventQuery(g_turn_ev[d]) != hipErrorNotReady)) break;
+                    if (s.next == s.serving && (!g_turn_ev_set[d] || hipEventQuery(g_turn_ev[d]) != hipErrorNotReady)) { gaveup = true; break; }
                 }
                 s.cv.wait_for(lk, std::chrono::microseconds(40));
+            }
+            s.window_deferred++;
+            if (gaveup) { s.window_gaveup++; s.total_gaveup++; ctx->n_gaveup++; }
+            if (s.window_deferred >= 4) {
+                if (s.window_gaveup >= 2) {
+                    if (++s.fail_streak >= 2) { s.hold = s.hold_len; if (s.hold_len < 8192) s.hold_len *= 2; }
+                } else { s.fail_streak = 0; s.hold_len = 64; }
+                s.window_deferred = s.window_gaveup = 0;
             }
             s.busy = true;
             st = P2;

@@ -123,7 +123,8 @@ class Segmenter:
                     slow_path_calls=int(self.L.pseg_tuning_state(self.h, 2)), fill_by_rows=bool(self.L.pseg_tuning_state(self.h, 3)),
                     band_order=int(self.L.pseg_tuning_state(self.h, 4)), band_order_fallbacks=int(self.L.pseg_tuning_state(self.h, 5)),
                     bg_streaming=int(self.L.pseg_tuning_state(self.h, 6)), fills_deferred=int(self.L.pseg_tuning_state(self.h, 7)),
-                    calls_on_streaming_queue=int(self.L.pseg_tuning_state(self.h, 8)))
+                    calls_on_streaming_queue=int(self.L.pseg_tuning_state(self.h, 8)),
+                    deferred_fills_given_up=int(self.L.pseg_tuning_state(self.h, 9)))
 
     def last_ms(self, which):
         return float(self.L.pseg_last_ms(self.h, which))

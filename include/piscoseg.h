@@ -209,7 +209,10 @@ float pseg_last_ms(const pseg_ctx *ctx, int which);
  * 7 = calls of this context whose label-map write was deferred behind the next call's background kernel (several contexts
  * in flight on one GPU: the labelling of a batch then runs beside the previous batch's label-map write; DESIGN.md section 3;
  * PSEG_DEFER_FILL=0 turns it off), 8 = calls whose background kernel and label-map write were queued on the device's shared
- * streaming queue instead of the context's own stream (PSEG_STREAM_QUEUE=0 turns that off).
+ * streaming queue instead of the context's own stream (PSEG_STREAM_QUEUE=0 turns that off), 9 = deferred writes of this
+ * context that were queued because the next call had not come by the time the device ran out of streaming work (callers
+ * that resubmit slowly: when 2 of 4 deferred writes on a device end that way twice in a row, the device keeps the plain order
+ * for its next 64 calls, then tries again, backing off to 128, 256 ... 8192 calls while the trials keep failing).
  * Returns -1 for a bad argument. */
 long long pseg_tuning_state(const pseg_ctx *ctx, int which);
 

@@ -12,7 +12,8 @@ from collections import defaultdict
 # kernel name prefix -> group (template arguments vary: k_bg_stream<false>, k_runs_band<10>, ...); everything else that starts
 # with k_ belongs to the sparse labelling chain
 PREFIX = [("k_bg_stream", "bg_correct"), ("k_bg_generic", "bg_correct"), ("k_reduce_partials", "bg_correct"), ("k_label_fill", "label_map"),
-          ("k_crops_sums", "crops_props"), ("k_convex", "crops_props"), ("k_band_map", "crops_props"), ("k_pack_out", "crops_props")]
+          ("k_crops_sums", "crops_props"), ("k_convex", "crops_props"), ("k_band_map", "crops_props"), ("k_pack_out", "crops_props"),
+          ("k_props", "crops_props")]
 SKIP = ("k_synth", "k_fill_spans", "__amd", "k_mask_count")
 
 

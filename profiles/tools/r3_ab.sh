@@ -20,7 +20,7 @@ for v in $WL; do
 import json,sys
 d=json.load(open(sys.argv[1]))
 g=d["roofline_groups"]
-print(f"{sys.argv[2]:44s} {d['value']:9.0f} f/s  {d['ms_per_step']:7.3f} ms/step  path {d['path']['frac_of_hbm_peak_per_gpu']:.3f} ", {k[:6]:(v["avg_ms"],v["avg_ms_alone"]) for k,v in g.items()})
+print(f"{sys.argv[2]:44s} {d['value']:9.0f} f/s  {d['ms_per_step']:7.3f} ms/step  path {d['path']['frac_of_hbm_peak_per_gpu']:.3f} def {d['path'].get('fills_deferred')}/{d['path'].get('deferred_fills_given_up')}", {k[:6]:(v["avg_ms"],v["avg_ms_alone"]) for k,v in g.items()})
 PY
 done
 done
