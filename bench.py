@@ -552,6 +552,10 @@ def main():
                      "traffic_source": None if dom["counter_bytes"] is None else "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
                                        "of this code kept from the build session (profiles/README.md), scaled to this launch's frames; "
                                        "not collected in this run", "avg_launch_ms": dom["avg_ms"],
+                     # the same kernel group with the GPU to itself (one call after the timed region): in the pipeline the label fill
+                     # shares the device with the next call's labelling chain, the background kernel with the previous call's crops
+                     "avg_launch_ms_alone": dom["avg_ms_alone"],
+                     "frac_alone": None if not dom["avg_ms_alone"] else round(dom["algorithmic_bytes"] / (dom["avg_ms_alone"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                      "bytes_per_launch": dom["algorithmic_bytes"], "frames_per_launch": round(frames_per_call, 1)},
         "roofline_groups": groups,
         "path": {"bytes_per_frame": path_bytes, "object_bytes_per_frame": round(obj_bytes, 1),

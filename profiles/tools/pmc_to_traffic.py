@@ -13,7 +13,11 @@ from collections import defaultdict
 # with k_ belongs to the sparse labelling chain
 PREFIX = [("k_bg_stream", "bg_correct"), ("k_bg_generic", "bg_correct"), ("k_reduce_partials", "bg_correct"), ("k_label_fill", "label_map"),
           ("k_crops_sums", "crops_props"), ("k_convex", "crops_props"), ("k_band_map", "crops_props"), ("k_pack_out", "crops_props"),
-          ("k_props", "crops_props")]
+          ("k_props", "crops_props"),
+          # round 3: the table kernels (boxes, areas, ranks, rows, size scans) left the labelling chain (k_rank_ext feeds the label fill)
+          ("k_rank_ext", "sparse_labelling"), ("k_bbox", "table_beside_label_map"), ("k_area", "table_beside_label_map"),
+          ("k_rank", "table_beside_label_map"), ("k_scan_small", "table_beside_label_map"), ("k_emit", "table_beside_label_map"),
+          ("k_scan_sizes", "table_beside_label_map")]
 SKIP = ("k_synth", "k_fill_spans", "__amd", "k_mask_count")
 
 

@@ -38,6 +38,6 @@ for f in sorted(glob.glob(f"gpurun_out/{P}_bench_*.json")):
     try: d = json.loads(open(f).read().strip().splitlines()[-1])
     except Exception as e: print(f, "unreadable", e); continue
     g = d["roofline_groups"]
-    print(f"{f.split('_bench_')[1][:-5]:18s} {d['value']:9.0f} f/s {d['ms_per_step']:7.3f} ms/step path {d['path']['frac_of_hbm_peak_per_gpu']:.3f} roofline {d['roofline']['kernel']} {d['roofline']['frac']:.3f} deferred {d["path"].get("fills_deferred")} gaveup {d["path"].get("deferred_fills_given_up")}",
+    print(f"{f.split('_bench_')[1][:-5]:18s} {d['value']:9.0f} f/s {d['ms_per_step']:7.3f} ms/step path {d['path']['frac_of_hbm_peak_per_gpu']:.3f} roofline {d['roofline']['kernel']} {d['roofline']['frac']:.3f} deferred {d['path'].get('fills_deferred')} gaveup {d['path'].get('deferred_fills_given_up')}",
           {k[:6]: (v["avg_ms"], v["avg_ms_alone"]) for k, v in g.items()}, d.get("cpu_baseline", {}).get("value"))
 PY
