@@ -394,13 +394,16 @@ def main():
             inflight = []
             for i in range(total):
                 k = i % ns
+                finished = None
                 if len(inflight) == ns:
                     i0, k0 = inflight.pop(0)
-                    done(i0, k0, segs[k0].wait()[3])
+                    finished = (i0, k0, segs[k0].wait()[3], {g: segs[k0].last_ms(g) for g in GROUP_NAMES})
                 c = i % nc
                 a, ne, na, _ = calls[c]
-                segs[k].submit(stack[a:a + na], **kwargs(c, k))
-                inflight.append((i, k))
+                segs[k].submit(stack[a:a + na], **kwargs(c, k))     # (the context goes back to work before its table is looked at:
+                inflight.append((i, k))                              # the table is a copy, and the group times were read above)
+                if finished is not None:
+                    done(*finished)
             for i0, k0 in inflight:
                 done(i0, k0, segs[k0].wait()[3])
         else:
