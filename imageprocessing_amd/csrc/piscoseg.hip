@@ -395,12 +395,12 @@ static int check_batch(pseg_ctx *ctx, int n)
 // Several contexts (host threads) share a GPU so that the host part of one batch (table formatting, 0.4 ms) hides under the
 // kernels of another.  Letting the kernels of two batches interleave as well is a loss on this path: the streaming kernels
 // need every wave slot and the whole memory system (two label fills side by side take 2.9 ms instead of 2 x 0.8 ms; a fill
-// next to the other batch's labelling kernels 1.4 ms, measured with rocprofv3 kernel traces, profiles/README.md).  The
-// streaming part of a call (background kernel, labelling, label fill) therefore runs under a per-device turn.  The turn is
-// handed on behind the label fill: the crop / property / hull kernels that follow wait on memory latency, and the next
-// batch's background kernel runs beside them at a small loss (0.92 ms for both against 0.65 + 0.38 ms one after the other).
-// Other pairings were traced and dropped: the crop chain beside the next batch's labelling kernels (both stretch: 0.64 ms
-// against 0.40 + 0.38 ms, and the background kernel alone again) comes out level.
+// next to the other batch's labelling kernels 1.4 ms -- with the fill's tables cold, as round 3 found --, measured with
+// rocprofv3 kernel traces, profiles/README.md).  Rounds 1 and 2 therefore ran the streaming part of a call (background kernel,
+// labelling, label fill) under a per-device turn, handed on behind the label fill: the crop / property / hull kernels that
+// follow wait on memory latency, and the next batch's background kernel runs beside them at a small loss (0.92 ms for both
+// against 0.65 + 0.38 ms one after the other).  With one or two calls in flight that is still the order of things; round 3
+// split the turn into two sections (below).
 // Schedule of one device.  The STREAMING kernels of all contexts (background kernel, label fill) run one at a time, in the order
 // in which the host queued them: each waits for the event recorded behind the one queued before it (g_turn_ev).  A call queues
 // them in two sections:
