@@ -105,6 +105,7 @@ struct pseg_ctx {
     bool early_release = true;    // hand the turn on behind the label fill instead of behind the last kernel (PSEG_EARLY_RELEASE=0)
     int fill_refresh = 2;         // PSEG_FILL_REFRESH=0: a deferred label fill reads its tables as the caches hold them (k_refresh_tables);
                                   // 1: refreshed in front of the fill; 2: beside its start when the fill is on the streaming queue
+    bool defer_test_giveup = false;   // PSEG_DEFER_FILL=2 (tests): a deferred fill does not wait and counts as given up
     bool stream_queue = true;     // PSEG_STREAM_QUEUE=0: the streaming kernels of a call that plans to defer its fill stay on the context's stream
     hipEvent_t ev_b = nullptr;    // hand-overs between the context's stream and the device's streaming queue
     bool defer_fill = true;       // PSEG_DEFER_FILL=0: a call's label fill never waits for the next call's background kernel (DevSched)
@@ -290,7 +291,7 @@ extern "C" int pseg_create(int device, int H, int W, int max_frames, pseg_ctx **
     }
     if (const char *e = getenv("PSEG_EXCLUSIVE")) ctx->exclusive = atoi(e) != 0;
     if (const char *e = getenv("PSEG_EARLY_RELEASE")) ctx->early_release = atoi(e) != 0;
-    if (const char *e = getenv("PSEG_DEFER_FILL")) ctx->defer_fill = atoi(e) != 0;
+    if (const char *e = getenv("PSEG_DEFER_FILL")) { ctx->defer_fill = atoi(e) != 0; ctx->defer_test_giveup = atoi(e) == 2; }
     if (const char *e = getenv("PSEG_STREAM_QUEUE")) ctx->stream_queue = atoi(e) != 0;
     if (hipEventCreateWithFlags(&ctx->ev_b, hipEventDisableTiming) != hipSuccess) ctx->ev_b = nullptr;
     if (const char *e = getenv("PSEG_FILL_REFRESH")) ctx->fill_refresh = atoi(e);
@@ -567,6 +568,7 @@ struct GpuTurn {
                     if (s.p1_done > mine) break;             // the next call has queued its background kernel
                     // nobody on the way and nothing streaming left on the device: waiting longer would leave it idle
                     if (s.next == s.serving && (!g_turn_ev_set[d] || hipEventQuery(g_turn_ev[d]) != hipErrorNotReady)) { gaveup = true; break; }
+                    if (ctx->defer_test_giveup) { gaveup = true; break; }   // (test of the hold: every deferred fill counts as given up)
                 }
                 s.cv.wait_for(lk, std::chrono::microseconds(40));
             }

@@ -97,6 +97,47 @@ def test_pipelined_submissions_equal_synchronous_calls(monkeypatch, ncontexts, e
             s.close()
 
 
+def test_deferred_fills_that_give_up_put_the_device_on_hold(monkeypatch):
+    """callers that resubmit too slowly for deferred fills to pay: after two windows of 4 deferred fills in which 2 or more gave up
+    (PSEG_DEFER_FILL=2 makes every one count as given up) the device keeps the plain order for 64 calls, then tries one window
+    again and backs off further; results stay those of the synchronous calls"""
+    import torch
+    from imageprocessing_amd import synth
+    from imageprocessing_amd.engine import Segmenter
+    H, W, n, nbatch = 128, 192, 16, 90
+    monkeypatch.setenv("PSEG_DEFER_FILL", "2")
+    objs, off = synth.make_objects(n, H, W, 71, per_frame=8, dmin=20, dmax=300)
+    frames = torch.from_numpy(synth.render(n, H, W, 71, objs, off)).cuda()
+    mask = torch.from_numpy(helpers.make_disk(H, W, 60)).cuda()
+    ref = Segmenter(H, W, max_frames=n, device=0)
+    lab0 = torch.empty((n, H, W), dtype=torch.int32, device="cuda")
+    want = ref.process(frames, mask=mask, labels=lab0, fetch_crops=True)
+    ref.close()
+    segs = [Segmenter(H, W, max_frames=n, device=0) for _ in range(3)]
+    try:
+        labs = [torch.empty((n, H, W), dtype=torch.int32, device="cuda") for _ in segs]
+        inflight = []
+        for b in range(nbatch):
+            k = b % 3
+            if len(inflight) == 3:
+                k0 = inflight.pop(0)
+                c, ms, v, tab = segs[k0].wait(fetch_crops=True)
+                _same_table(tab, want[3])
+                assert torch.equal(labs[k0], lab0) and torch.equal(c, want[0])
+            segs[k].submit(frames, mask=mask, labels=labs[k])
+            inflight.append(k)
+        for k0 in inflight:
+            segs[k0].wait()
+        st = [s_.tuning_state() for s_ in segs]
+        n_def = sum(t["fills_deferred"] for t in st)
+        n_gu = sum(t["deferred_fills_given_up"] for t in st)
+        assert n_def == n_gu                                  # every deferred fill gave up ...
+        assert n_def <= 8 + 4                                 # ... so two windows of 4, a hold of 64 calls, at most one more window
+    finally:
+        for s in segs:
+            s.close()
+
+
 def test_submit_wait_protocol_and_errors():
     import torch
     from imageprocessing_amd.engine import PsegError, Segmenter
