@@ -237,7 +237,16 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+            # (no device_id: the communicator -- and RCCL's streams -- come up with the first collective, in the warm-up, after
+            # the library's contexts have created theirs.  A process has four hardware queues and a new stream goes to the one
+            # with the fewest users: with RCCL's streams first, two contexts' streams shared a queue and the crop tail of one
+            # call sat behind the whole next call -- kernel trace in profiles/r03/23_frame_sharded_queues.txt.  Which queues get
+            # shared stays a lottery either way: 102 400 - 105 400 frames/s in seven --force-dist runs with the eager
+            # communicator, 99 000 - 105 700 in four with this order.  BENCH_EAGER_COMM=1: the old order)
+            if os.environ.get("BENCH_EAGER_COMM"):
+                dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+            else:
+                dist.init_process_group("nccl")
         else:
             dist.init_process_group("gloo")
     torch.cuda.set_device(local_rank)
@@ -392,18 +401,27 @@ def main():
                 state["gat"].finish(timed)
         if args.driver == "submit":
             inflight = []
+            hp = [] if os.environ.get("BENCH_HOST_PROF") else None   # (diagnostic: host time per loop turn in wait / submit / done, to stderr)
             for i in range(total):
                 k = i % ns
                 finished = None
+                ta = time.perf_counter()
                 if len(inflight) == ns:
                     i0, k0 = inflight.pop(0)
                     finished = (i0, k0, segs[k0].wait()[3], {g: segs[k0].last_ms(g) for g in GROUP_NAMES})
+                tb = time.perf_counter()
                 c = i % nc
                 a, ne, na, _ = calls[c]
                 segs[k].submit(stack[a:a + na], **kwargs(c, k))     # (the context goes back to work before its table is looked at:
                 inflight.append((i, k))                              # the table is a copy, and the group times were read above)
+                tc = time.perf_counter()
                 if finished is not None:
                     done(*finished)
+                if hp is not None:
+                    hp.append((tb - ta, tc - tb, time.perf_counter() - tc))
+            if hp and timed:
+                h = np.array(hp) * 1e3
+                print("host prof (ms) wait/submit/done mean", h.mean(0).round(3), "p99", np.percentile(h, 99, axis=0).round(3), "max", h.max(0).round(3), file=sys.stderr)
             for i0, k0 in inflight:
                 done(i0, k0, segs[k0].wait()[3])
         else:
