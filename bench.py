@@ -237,16 +237,16 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
-            # (no device_id: the communicator -- and RCCL's streams -- come up with the first collective, in the warm-up, after
-            # the library's contexts have created theirs.  A process has four hardware queues and a new stream goes to the one
-            # with the fewest users: with RCCL's streams first, two contexts' streams shared a queue and the crop tail of one
-            # call sat behind the whole next call -- kernel trace in profiles/r03/23_frame_sharded_queues.txt.  Which queues get
-            # shared stays a lottery either way: 102 400 - 105 400 frames/s in seven --force-dist runs with the eager
-            # communicator, 99 000 - 105 700 in four with this order.  BENCH_EAGER_COMM=1: the old order)
-            if os.environ.get("BENCH_EAGER_COMM"):
-                dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
-            else:
+            # (device_id: the communicator -- and RCCL's streams -- come up now, before the library's contexts create theirs.  A
+            # process has four hardware queues and a stream goes to the one with the fewest users when it is first used; which
+            # streams end up sharing one is a lottery the program cannot see -- a kernel trace with two contexts on one queue is in
+            # profiles/r03/23_frame_sharded_queues.txt -- and six alternating pairs of --force-dist runs gave 102 800 - 105 300
+            # frames/s this way round against 98 400 - 103 700 with the communicator created at the first collective
+            # (BENCH_LAZY_COMM=1))
+            if os.environ.get("BENCH_LAZY_COMM"):
                 dist.init_process_group("nccl")
+            else:
+                dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
         else:
             dist.init_process_group("gloo")
     torch.cuda.set_device(local_rank)
