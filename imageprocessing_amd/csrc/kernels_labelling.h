@@ -123,7 +123,10 @@ __global__ void k_unions(SegState S, int nfg, int nt, int bandh)
 // batch, [F + 1] = largest band, [F + 2] = error flag of the look-back scan.
 __device__ __forceinline__ bool chain_ok(const SegState &S, uint32_t cap, uint32_t bcap)
 {
-    return S.framebase[S.F] <= cap && S.framebase[S.F + 1] <= bcap && S.framebase[S.F + 2] == 0;   // (a scan that timed out left no usable tables)
+    // (the three words are requested together: with && the compiler waits for each before it asks for the next, three scalar-cache
+    // round trips at the head of every wave of every kernel of the chain)
+    const uint32_t a = S.framebase[S.F], b = S.framebase[S.F + 1], c = S.framebase[S.F + 2];
+    return (a <= cap) & (b <= bcap) & (c == 0);             // (c: a scan that timed out left no usable tables)
 }
 // unions across the band boundaries only: block = the first row of a band (y = BAND_H, 2 BAND_H, ...) of one frame, a
 // thread per run (its foreground unions with the row above, and the gap on its left) plus one for the trailing gap.  The

@@ -103,9 +103,16 @@ typedef int32_t i32x4_t __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void k_label_fill(SegState S, const int32_t *__restrict__ runlabel, int32_t *__restrict__ labels,
                                                     uint32_t cap, uint32_t bcap)
 {
-    if (!chain_ok(S, cap, bcap)) return;                    // (queued with the chain: see chain_ok)
     const int lane = threadIdx.x & 63;
     const int f = blockIdx.z, y = blockIdx.y;
+    // (the row's place in the run tables is requested together with the chain's totals, before either is looked at: a wave lives for
+    // about a microsecond, most of it dependent loads -- kernel arguments, totals, row offsets, runs -- and the kernel's rate is
+    // the number of waves in flight over that time; the offsets lie inside the table whatever the chain did)
+    uint32_t t0 = S.framebase[S.F], t1 = S.framebase[S.F + 1], t2 = S.framebase[S.F + 2];
+    uint32_t r0 = S.rowoff[f * (S.H + 1) + y], r1 = S.rowoff[f * (S.H + 1) + y + 1];
+    asm volatile("" : "+s"(t0), "+s"(t1), "+s"(t2), "+s"(r0), "+s"(r1));      // (all five here: the compiler would sink the offsets below the test)
+    if (!((t0 <= cap) & (t1 <= bcap) & (t2 == 0))) return;  // chain_ok (queued with the chain)
+    const int rs = (int)r0, n = (int)(r1 - r0);
     const int x0 = blockIdx.x * 1024 + (threadIdx.x >> 6) * 256, x = x0 + 4 * lane;
     if (x0 >= S.W) return;                                   // wave beyond the row end
     const bool in = x < S.W;
@@ -115,7 +122,6 @@ __global__ __launch_bounds__(256) void k_label_fill(SegState S, const int32_t *_
     // costs the stores more than the lookups do.  (One bit per row and span left by k_runs_band -- "no foreground here", 2 MB per
     // batch read through the scalar cache, seven spans in ten stored without a look at the run tables -- made the kernel slower:
     // 1.205 against 1.087 ms, four alternating runs on one box, round 3.)
-    const int rs = seg_rowstart(S, f, y), n = seg_rowcount(S, f, y);
     {
         for (int j0 = 0; j0 < n; j0 += 64) {
             uint32_t rx = 0xffffu; int lab = 0;              // lanes past the row's runs: xs = 65535, xe = 0
